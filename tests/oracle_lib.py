@@ -1,0 +1,219 @@
+"""ctypes view of oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg load this module; the
+product package (whisper_amd/) never does.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_lib = C.CDLL(os.path.join(_ROOT, "oracle", "liboracle.so"))
+
+SUMVEC, HISTOGRAM, AVERAGE = 0, 1, 2
+P128 = 2**128 - 7 * 2**66 + 1
+
+OK, ERR_PARAM, ERR_SHORT, ERR_MODULUS, ERR_AGG_ID, ERR_NUM_QUERIES, ERR_QUERY_RAND = 0, -1, -2, -3, -4, -5, -6
+
+
+class Params(C.Structure):
+    _fields_ = [("circuit", C.c_uint32), ("bits", C.c_uint32), ("len", C.c_uint32), ("chunk", C.c_uint32),
+                ("num_aggregators", C.c_uint32), ("id", C.c_uint32)]
+
+
+class Sizes(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in (
+        "input_len", "proof_len", "verifier_len", "output_len", "joint_rand_len", "prove_rand_len",
+        "query_rand_len", "calls", "m", "arity", "leader_report_len", "helper_report_len")]
+
+
+def params(circuit, bits=0, length=0, chunk=0, num_aggregators=2, alg_id=0):
+    return Params(circuit, bits, length, chunk, num_aggregators, alg_id)
+
+
+def sizes(p):
+    s = Sizes()
+    rc = _lib.wo_sizes_of(C.byref(p), C.byref(s))
+    if rc:
+        raise ValueError(f"bad params rc={rc}")
+    return s
+
+
+def _buf(n):
+    return (C.c_uint8 * n)()
+
+
+def _b(x):
+    return (C.c_uint8 * len(x)).from_buffer_copy(bytes(x))
+
+
+def f_enc(v):
+    return int(v % P128).to_bytes(16, "little")
+
+
+def f_dec(b):
+    return int.from_bytes(bytes(b), "little")
+
+
+def f_mul(a, b):
+    o = _buf(16); _lib.wo_f128_mul(_b(f_enc(a)), _b(f_enc(b)), o); return f_dec(o)
+
+
+def f_add(a, b):
+    o = _buf(16); _lib.wo_f128_add(_b(f_enc(a)), _b(f_enc(b)), o); return f_dec(o)
+
+
+def f_sub(a, b):
+    o = _buf(16); _lib.wo_f128_sub(_b(f_enc(a)), _b(f_enc(b)), o); return f_dec(o)
+
+
+def f_inv(a):
+    o = _buf(16); _lib.wo_f128_inv(_b(f_enc(a)), o); return f_dec(o)
+
+
+def f_constants():
+    p, r2, g = _buf(16), _buf(16), _buf(16)
+    mu = C.c_uint64()
+    _lib.wo_f128_constants(p, r2, g, C.byref(mu))
+    return f_dec(p), f_dec(r2), f_dec(g), mu.value
+
+
+def f_root(l):
+    o = _buf(16); _lib.wo_f128_root(C.c_uint(l), o); return f_dec(o)
+
+
+def shake128(data, n):
+    o = _buf(n); _lib.wo_shake128(_b(data) if data else None, C.c_size_t(len(data)), o, C.c_size_t(n)); return bytes(o)
+
+
+def xof_expand(seed, dst, binder, n):
+    o = _buf(16 * n)
+    _lib.wo_xof_expand_f128(_b(seed), _b(dst), C.c_size_t(len(dst)), _b(binder) if binder else None,
+                            C.c_size_t(len(binder)), C.c_size_t(n), o)
+    return bytes(o)
+
+
+def xof_derive_seed(seed, dst, binder):
+    o = _buf(16)
+    _lib.wo_xof_derive_seed(_b(seed), _b(dst), C.c_size_t(len(dst)), _b(binder) if binder else None,
+                            C.c_size_t(len(binder)), o)
+    return bytes(o)
+
+
+def fft(vals, size, inverse=False):
+    inp = b"".join(f_enc(v) for v in vals)
+    o = _buf(16 * size)
+    fn = _lib.wo_ifft_f128 if inverse else _lib.wo_fft_f128
+    rc = fn(_b(inp), C.c_size_t(len(vals)), C.c_size_t(size), o)
+    assert rc == 0
+    return [f_dec(bytes(o)[16 * i:16 * i + 16]) for i in range(size)]
+
+
+def _meas(meas):
+    if isinstance(meas, int):
+        meas = [meas]
+    return (C.c_uint64 * len(meas))(*meas)
+
+
+def flp_encode(p, meas):
+    s = sizes(p); o = _buf(16 * s.input_len)
+    rc = _lib.wo_flp_encode(C.byref(p), _meas(meas), o); assert rc == 0, rc
+    return bytes(o)
+
+
+def flp_prove(p, inp, prove_rand, joint_rand):
+    s = sizes(p); o = _buf(16 * s.proof_len)
+    rc = _lib.wo_flp_prove(C.byref(p), _b(inp), _b(prove_rand), _b(joint_rand), o); assert rc == 0, rc
+    return bytes(o)
+
+
+def flp_query(p, inp, proof, query_rand, joint_rand, num_shares):
+    s = sizes(p); o = _buf(16 * s.verifier_len)
+    rc = _lib.wo_flp_query(C.byref(p), _b(inp), _b(proof), _b(query_rand), _b(joint_rand), C.c_uint32(num_shares), o)
+    return rc, bytes(o)
+
+
+def flp_decide(p, verifier):
+    return bool(_lib.wo_flp_decide(C.byref(p), _b(verifier)))
+
+
+def flp_truncate(p, inp):
+    s = sizes(p); o = _buf(16 * s.output_len)
+    rc = _lib.wo_flp_truncate(C.byref(p), _b(inp), o); assert rc == 0
+    return bytes(o)
+
+
+def prio3_shard(p, meas, nonce, rand):
+    s = sizes(p); na = p.num_aggregators
+    ps = _buf(16 * na); ls = _buf(16 * (s.input_len + s.proof_len) + 16); hs = _buf(48 * (na - 1))
+    rc = _lib.wo_prio3_shard(C.byref(p), _meas(meas), _b(nonce), _b(rand), ps, ls, hs); assert rc == 0, rc
+    hs = bytes(hs)
+    return bytes(ps), [bytes(ls)] + [hs[48 * i:48 * i + 48] for i in range(na - 1)]
+
+
+def prio3_prepare_init(p, verify_key, agg_id, nonce, public_share, input_share):
+    s = sizes(p)
+    prep = _buf(16 * s.verifier_len + 16); out = _buf(16 * s.output_len)
+    rc = _lib.wo_prio3_prepare_init(C.byref(p), _b(verify_key), C.c_uint32(agg_id), _b(nonce), _b(public_share),
+                                    _b(input_share), C.c_size_t(len(input_share)), prep, out)
+    return rc, bytes(prep), bytes(out)
+
+
+def prio3_shard_batched(p, meas, nonce, rand, client_id):
+    s = sizes(p)
+    lr = _buf(s.leader_report_len); hr = _buf(s.helper_report_len)
+    rc = _lib.wo_prio3_shard_batched(C.byref(p), _meas(meas), _b(nonce), _b(rand), _b(int(client_id).to_bytes(16, "big")), lr, hr)
+    assert rc == 0, rc
+    return bytes(lr), bytes(hr)
+
+
+def prio3_prepare_encoded_key(p, verify_key, report):
+    s = sizes(p)
+    tag = _buf(16); tid = _buf(16); out = _buf(16 * s.output_len)
+    rc = _lib.wo_prio3_prepare_encoded_key(C.byref(p), _b(verify_key), _b(report), C.c_size_t(len(report)), tag, tid, out)
+    return rc, bytes(tag), bytes(tid), bytes(out)
+
+
+def prio3_prepare_batch(p, verify_key, blob, offsets, nthreads=1):
+    """blob: bytes/np.uint8 array; offsets: n+1 uint64.  Returns (tags[n,16], ids[n,16], status[n], out_shares[n,output_len*16])."""
+    s = sizes(p)
+    blob = np.ascontiguousarray(np.frombuffer(blob, dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = len(offsets) - 1
+    tags = np.zeros((n, 16), np.uint8); ids = np.zeros((n, 16), np.uint8)
+    status = np.zeros(n, np.int32); outs = np.zeros((n, 16 * s.output_len), np.uint8)
+    _lib.wo_prio3_prepare_batch.argtypes = [C.c_void_p] * 4 + [C.c_uint64, C.c_uint] + [C.c_void_p] * 4
+    rc = _lib.wo_prio3_prepare_batch(C.cast(C.byref(p), C.c_void_p), C.cast(_b(verify_key), C.c_void_p), blob.ctypes.data,
+                                     offsets.ctypes.data, n, nthreads, tags.ctypes.data, ids.ctypes.data,
+                                     status.ctypes.data, outs.ctypes.data)
+    assert rc == 0, rc
+    return tags, ids, status, outs
+
+
+def prio3_aggregate(out_shares, output_len, keep=None):
+    out_shares = np.ascontiguousarray(out_shares, dtype=np.uint8)
+    n = out_shares.shape[0]
+    agg = np.zeros(16 * output_len, np.uint8)
+    keep_p = None
+    if keep is not None:
+        keep = np.ascontiguousarray(keep, dtype=np.uint8); keep_p = keep.ctypes.data
+    _lib.wo_prio3_aggregate.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
+    _lib.wo_prio3_aggregate(out_shares.ctypes.data, n, output_len, keep_p, agg.ctypes.data)
+    return agg
+
+
+def aes128_encrypt_block(key, block):
+    o = _buf(16); _lib.wo_aes128_encrypt_block(_b(key), _b(block), o); return bytes(o)
+
+
+def hh_bucket_sum_u32(buckets, keep=None):
+    buckets = np.ascontiguousarray(buckets, dtype=np.uint32)
+    n, words = buckets.shape[0], int(np.prod(buckets.shape[1:]))
+    acc = np.zeros(words, np.uint32)
+    keep_p = None
+    if keep is not None:
+        keep = np.ascontiguousarray(keep, dtype=np.uint8); keep_p = keep.ctypes.data
+    _lib.wo_hh_bucket_sum_u32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+    _lib.wo_hh_bucket_sum_u32(buckets.ctypes.data, keep_p, n, words, acc.ctypes.data)
+    return acc.reshape(buckets.shape[1:])
