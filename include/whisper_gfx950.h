@@ -1,0 +1,144 @@
+/*
+ * whisper_gfx950.h -- C ABI of libwhisper_gfx950.so: the MI355X (gfx950) implementation of
+ * ucbsky/whisper's server hot path (batched FLPCP verification + share aggregation).
+ *
+ * This is the drop-in boundary.  The reference has no FFI seam of its own: the path sits behind
+ * Rust traits, so each entry point below names the reference interface it replaces.  All
+ * functions return an int32 status (0 = ok, negative = error), never throw, and take plain
+ * pointers and sizes.  One context per GPU; a context is used by one thread at a time.
+ *
+ * Encodings are the reference's own: reports are `VdafBatchedKey::get_encoded()` bytes
+ * (batched-flpcp-rs/src/vdaf.rs:148-162), field elements are 16-byte little-endian canonical
+ * residues (field.rs:598-607), testing ids are u128 little-endian.
+ */
+#ifndef WHISPER_GFX950_H
+#define WHISPER_GFX950_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wh_ctx wh_ctx;
+
+/* Circuit selector: bin-utils/src/lib.rs:18-32 `AggFunc` / `Prio3Gadgets`. */
+enum { WH_SUMVEC = 0, WH_HISTOGRAM = 1, WH_AVERAGE = 2 };
+
+/* Instance parameters: the arguments of Prio3::new_sum_vec_256 / new_histogram_256 /
+ * new_average_256 (vdaf/prio3.rs:150-165, 300-313, 360-380) as the servers call them
+ * (server-batch-prio3/src/main.rs:249-257).  num_aggregators must be 2 (Alice and Bob). */
+typedef struct {
+    uint32_t circuit;         /* WH_SUMVEC | WH_HISTOGRAM | WH_AVERAGE */
+    uint32_t bits;            /* SumVec: 16 in the servers; Average: AVG_BITS = 64 */
+    uint32_t len;             /* SumVec vec_size / Histogram length */
+    uint32_t chunk;           /* chunk_size */
+    uint32_t num_aggregators; /* 2 */
+    uint32_t reserved;        /* 0 */
+} wh_prio3_params;
+
+/* Derived sizes (flp/types.rs:650-676, 444-470, 286-312; report sizes from vdaf.rs:148-162). */
+typedef struct {
+    uint32_t input_len, proof_len, verifier_len, output_len;
+    uint32_t joint_rand_len, calls, m, arity;
+    uint32_t leader_report_len, helper_report_len;
+} wh_prio3_sizes;
+
+/* Per-report status = the reference's failure classes.  Every non-zero value is an
+ * unwrap()/assert abort in server-batch-prio3 (main.rs:46-49); here the report is skipped. */
+enum {
+    WH_OK = 0,
+    WH_ERR_PARAM = -1,
+    WH_ERR_SHORT = -2,        /* CodecError: input ends early (codec.rs) */
+    WH_ERR_MODULUS = -3,      /* FieldError::ModulusOverflow (field.rs:417-419) */
+    WH_ERR_AGG_ID = -4,       /* "unexpected aggregator id" (prio3.rs:1496-1501) */
+    WH_ERR_NUM_QUERIES = -5,  /* public proof length != verifier length (prio3.rs:2712) */
+    WH_ERR_QUERY_RAND = -6,   /* FlpError::Query: r is an m-th root of unity (flp.rs:413-419) */
+    /* library-level */
+    WH_ERR_HIP = -100,
+    WH_ERR_NO_DEVICE = -101,
+    WH_ERR_STATE = -102,
+    WH_ERR_UNSUPPORTED = -103
+};
+
+/* ---- context ---- */
+/* replaces: Prio3::new_* + Prf::new (common/src/prg.rs:644-648).  Binds `device_id`. */
+int32_t wh_ctx_create(int32_t device_id, const wh_prio3_params *params, wh_ctx **out);
+void wh_ctx_destroy(wh_ctx *ctx);
+int32_t wh_prio3_sizes_of(const wh_prio3_params *params, wh_prio3_sizes *out);
+/* last HIP error text for this context (valid until the next call) */
+const char *wh_last_error(const wh_ctx *ctx);
+/* the HIP stream (hipStream_t) the context launches on, for callers that time or order work */
+void *wh_ctx_stream(wh_ctx *ctx);
+
+/* ---- batched verification ---- */
+/* replaces: the per-report loop of run_vdaf_prepare{,_rayon} over prepare_encoded_key
+ * (server-batch-prio3/src/main.rs:33-60, 75-91, 138-156) =
+ *   VdafBatchedKey::decode_with_param + Prio3::prepare_batched (vdaf/prio3.rs:2466-2879)
+ *   + Prf::compute_prf + tag negation for agg_id != 0.
+ * blob/offsets: n encoded reports back to back, offsets[n+1] (bytes).  All pointers are DEVICE
+ * pointers; nothing is copied to the host and the call returns after enqueueing on the context
+ * stream (wh_ctx_synchronize to wait).
+ *   tags        n*16   proof tags (already negated for Helper-role reports)
+ *   testing_ids n*16   u128 LE
+ *   status      n      int32 per report
+ * The out shares (truncated measurement shares) stay in the context for wh_prio3_aggregate*. */
+int32_t wh_prio3_prepare_batch_dev(wh_ctx *ctx, const uint8_t verify_key[16], const uint8_t *d_blob,
+                                   const uint64_t *d_offsets, uint64_t n, uint8_t *d_tags,
+                                   uint8_t *d_testing_ids, int32_t *d_status);
+/* Same with HOST buffers (what a Rust caller holding Vec<Vec<u8>> would use); copies in and out
+ * and synchronises. */
+int32_t wh_prio3_prepare_batch(wh_ctx *ctx, const uint8_t verify_key[16], const uint8_t *blob,
+                               const uint64_t *offsets, uint64_t n, uint8_t *tags, uint8_t *testing_ids,
+                               int32_t *status);
+/* replaces: Prio3::prepare_batched's second return value (OutputShare).  Copies the n*output_len
+ * out-share elements of the last batch to the host. */
+int32_t wh_prio3_out_shares(wh_ctx *ctx, uint8_t *out_shares);
+
+/* ---- aggregation ---- */
+/* replaces: the merge loop over reports whose testing id is not in the bad set
+ * (server-batch-prio3/src/main.rs:108-118, 173-183; Aggregatable::merge vdaf.rs:658-676;
+ * Prio3::aggregate prio3.rs:2445-2456).  keep[n]: 1 = aggregate, 0 = skip (NULL = keep all).
+ * Reports with non-zero status are never aggregated. */
+int32_t wh_prio3_aggregate_dev(wh_ctx *ctx, const uint8_t *d_keep, uint8_t *d_agg);
+int32_t wh_prio3_aggregate(wh_ctx *ctx, const uint8_t *keep, uint8_t *agg);
+/* replaces: AggregateShare::merge across partial aggregates (main.rs:327-335); with one process
+ * per GPU the rows are the RCCL all-gathered per-GPU partials.  d_rows[n_rows][len] -> d_out[len]. */
+int32_t wh_f128_sum_rows_dev(wh_ctx *ctx, const uint8_t *d_rows, uint64_t n_rows, uint32_t len,
+                             const uint8_t *d_keep, uint8_t *d_out);
+
+/* ---- heavy hitters ---- */
+/* replaces: aggregate_hhs' rayon reduce of Vec<Bucket<u32>> (server-hh/src/main.rs:72-104;
+ * Bucket::add hhcore/src/bucket.rs:48-55; u32 wrapping add common/src/group.rs:88-91).
+ * buckets[n][words] with words = num_buckets * 258 (256 data + sign + ctr); acc[words]. */
+int32_t wh_hh_bucket_sum_u32_dev(wh_ctx *ctx, const uint32_t *d_buckets, const uint8_t *d_keep, uint64_t n,
+                                 uint64_t words, uint32_t *d_acc);
+
+int32_t wh_ctx_synchronize(wh_ctx *ctx);
+
+/* ---- client side (CPU): input generator ---- */
+/* replaces: Prio3::shard_batched + VdafBatchedKey::get_encoded as client-batch-prio3 uses them
+ * (client-batch-prio3/src/main.rs:67-153; vdaf/prio3.rs:537-991).  `rand` is the 144-byte
+ * random string shard_with_random_new consumes; writes both encoded reports. */
+int32_t wh_client_shard_batched(const wh_prio3_params *params, const uint64_t *measurement,
+                                const uint8_t nonce[16], const uint8_t rand[144],
+                                const uint8_t client_id_be[16], uint8_t *leader_report,
+                                uint8_t *helper_report);
+/* many reports on `nthreads` host threads; measurements[n][meas_words], nonces[n][16],
+ * rands[n][144], client ids = first_client_id + i; reports written at leader_reports + i*leader_len
+ * and helper_reports + i*helper_len */
+int32_t wh_client_shard_many(const wh_prio3_params *params, const uint64_t *measurements, uint32_t meas_words,
+                             const uint8_t *nonces, const uint8_t *rands, uint64_t first_client_id, uint64_t n,
+                             uint32_t nthreads, uint8_t *leader_reports, uint8_t *helper_reports);
+
+/* ---- unit-parity surface (mirrors field.rs / xof.rs for kernel-level tests) ---- */
+/* op: 0 add, 1 sub, 2 mul, 3 inv(a).  Host buffers of n 16-byte elements. */
+int32_t wh_test_f128_op(wh_ctx *ctx, int32_t op, const uint8_t *a, const uint8_t *b, uint8_t *out, uint64_t n);
+/* per seed i: XofShake128::seed_stream(seed_i, dst(alg_id, usage), binder).into_field_vec(n_elems) */
+int32_t wh_test_xof_expand(wh_ctx *ctx, const uint8_t *seeds, uint64_t n, uint32_t alg_id, uint32_t usage,
+                           const uint8_t *binder, uint32_t binder_len, uint32_t n_elems, uint8_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

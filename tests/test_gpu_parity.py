@@ -1,0 +1,227 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  Bar: bit-exact (integer / byte work)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import whisper_amd as W
+from common import VK, blob_of, det, make_reports, server_views
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small_ctx():
+    v = W.new_sum_vec_256(2, 2, 5, 3)
+    yield v
+    v.close()
+
+
+def test_field_ops_bit_exact(small_ctx):
+    p = O.P128
+    rnd = np.random.default_rng(11)
+    edge = [0, 1, 2, p - 1, p - 2, 2**64 - 1, 2**64, 2**127, 7 * 2**66, p - 2**64, 2**128 - 2**66 * 7]
+    vals = edge + [int.from_bytes(rnd.bytes(16), "little") % p for _ in range(500)]
+    a = [vals[i % len(vals)] for i in range(2048)]
+    b = [vals[(i * 7 + i // len(vals)) % len(vals)] for i in range(2048)]
+    ab = np.frombuffer(b"".join(O.f_enc(x) for x in a), np.uint8)
+    bb = np.frombuffer(b"".join(O.f_enc(x) for x in b), np.uint8)
+    for op, fn in ((0, lambda x, y: (x + y) % p), (1, lambda x, y: (x - y) % p), (2, lambda x, y: x * y % p)):
+        out = small_ctx.test_f128_op(op, ab, bb).tobytes()
+        want = b"".join(O.f_enc(fn(x, y)) for x, y in zip(a, b))
+        assert out == want, op
+    out = small_ctx.test_f128_op(3, ab[:16 * 64]).tobytes()
+    for i in range(64):
+        got = O.f_dec(out[16 * i:16 * i + 16])
+        assert got == (pow(a[i], p - 2, p) if a[i] else 0)
+        assert got == O.f_inv(a[i])
+
+
+@pytest.mark.parametrize("n_elems,binder", [(1, b""), (2, b"\x01"), (10, b"x" * 16), (11, b""), (21, b"abc"), (22, b"q" * 143),
+                                            (255, b"\x01"), (2048, b"\x01")])
+def test_xof_expand_bit_exact(small_ctx, n_elems, binder):
+    seeds = det(b"seeds", 16 * 70).reshape(70, 16)
+    out = small_ctx.test_xof_expand(seeds, 2, 1, binder, n_elems)
+    dst = bytes([7, 0, 0, 0, 0, 2, 0, 1])
+    for i in (0, 1, 63, 64, 69):
+        assert out[i].tobytes() == O.xof_expand(seeds[i].tobytes(), dst, binder, n_elems)
+
+
+CASES = [
+    ("sumvec_2_5_3", (W.SUMVEC, 2, 5, 3), 9),
+    ("sumvec_ragged_16_3_7", (W.SUMVEC, 16, 3, 7), 8),
+    ("sumvec_cfg1_16_128_64", (W.SUMVEC, 16, 128, 64), 70),       # configs/prio3-server-alice.json
+    ("sumvec_chunk128", (W.SUMVEC, 16, 64, 128), 6),               # chunk wider than a wavefront
+    ("sumvec_chunk5_len40", (W.SUMVEC, 8, 40, 5), 5),              # many calls: m = 128
+    ("histogram_4_2", (W.HISTOGRAM, 0, 4, 2), 8),
+    ("histogram_11_3", (W.HISTOGRAM, 0, 11, 3), 8),
+    ("histogram_128_64", (W.HISTOGRAM, 0, 128, 64), 20),
+]
+
+
+def oracle_batch(op, reports):
+    blob, offsets = blob_of(reports)
+    return O.prio3_prepare_batch(op, VK, blob, offsets, nthreads=8)
+
+
+@pytest.mark.parametrize("name,cfg,n", CASES, ids=[c[0] for c in CASES])
+def test_prepare_and_aggregate_match_oracle(name, cfg, n):
+    circ, bits, ln, ch = cfg
+    p = W.Prio3Params(circ, bits, ln, ch)
+    op = O.params(circ, bits, ln, ch)
+    lr, hr, meas = make_reports(p, n, seed=len(name))
+    bad = {1, n - 2}
+    alice, bob = server_views(lr, hr, bad)
+    # malformed reports on Alice's side (decode / structure errors of vdaf.rs:164-192)
+    a_err = list(alice)
+    a_err.append(alice[0][:-1])                                   # short
+    a_err.append(alice[1][:30])                                   # short header
+    x = bytearray(alice[0]); x[48] = 2; a_err.append(bytes(x))    # agg id
+    x = bytearray(alice[0]); x[49:65] = (O.P128).to_bytes(16, "little"); a_err.append(bytes(x))   # meas >= p
+    x = bytearray(alice[2]); x[-40:-32] = b"\xff" * 8; x[-48:-40] = b"\xff" * 8; a_err.append(bytes(x))  # pp >= p
+    nq_off = 49 + 64 + 32
+    x = bytearray(alice[1]); x[nq_off:nq_off + 8] = (p.verifier_len - 1).to_bytes(8, "big"); a_err.append(bytes(x))
+    a_err.append(alice[0] + b"\x00" * 7)                          # trailing bytes are not looked at
+    x = bytearray(alice[0]); x[60] ^= 0x40; a_err.append(bytes(x))  # still canonical, wrong share -> bad tag
+
+    vdaf = W.Prio3(p)
+    try:
+        for reports in (a_err, bob):
+            tags, ids, status = vdaf.prepare_encoded_keys(VK, reports)
+            outs = vdaf.out_shares()
+            o_tags, o_ids, o_status, o_outs = oracle_batch(op, reports)
+            assert np.array_equal(status, o_status), (status, o_status)
+            ok = status == 0
+            assert np.array_equal(tags[ok], o_tags[ok])
+            assert np.array_equal(ids[ok], o_ids[ok])
+            assert np.array_equal(outs[ok], o_outs[ok])
+            keep = np.ones(len(reports), np.uint8)
+            keep[[1, 3]] = 0
+            agg = vdaf.aggregate(keep)
+            assert np.array_equal(agg, O.prio3_aggregate(o_outs, p.output_len, keep & ok.astype(np.uint8)))
+            assert np.array_equal(vdaf.aggregate(None), O.prio3_aggregate(o_outs, p.output_len, ok.astype(np.uint8)))
+        # the two servers: tags agree exactly on honest clients and differ on tampered ones
+        ta, _, sa = vdaf.prepare_encoded_keys(VK, alice)
+        agg_a = vdaf.aggregate(np.array([i not in bad for i in range(n)], np.uint8))
+        tb, _, sb = vdaf.prepare_encoded_keys(VK, bob)
+        agg_b = vdaf.aggregate(np.array([i not in bad for i in range(n)], np.uint8))
+        assert not sa.any() and not sb.any()
+        for i in range(n):
+            assert (ta[i].tobytes() != tb[i].tobytes()) == (i in bad)
+        # unshard over the good clients gives the true aggregate
+        total = W.Prio3.unshard([agg_a, agg_b])
+        good = [i for i in range(n) if i not in bad]
+        if circ == W.SUMVEC:
+            want = [int(sum(int(meas[i][e]) for i in good)) for e in range(ln)]
+        else:
+            want = [sum(1 for i in good if int(meas[i][0]) == e) for e in range(ln)]
+        assert total == want
+    finally:
+        vdaf.close()
+
+
+def test_end_to_end_group_test_identifies_bad_clients():
+    """C1 of BASELINE.md in miniature: Alice + Bob in one process, tags from the GPU, group testing
+    on the host, aggregate over the clients that pass (server-batch-prio3/src/main.rs:65-125)."""
+    p = W.Prio3Params(W.SUMVEC, 16, 16, 8)
+    n, bad = 200, {3, 17, 18, 101, 199}
+    lr, hr, meas = make_reports(p, n, seed=77)
+    alice, bob = server_views(lr, hr, bad)
+    vdaf = W.Prio3(p)
+    try:
+        views = []
+        for reports in (alice, bob):
+            tags, ids, status = vdaf.prepare_encoded_keys(VK, reports)
+            assert not status.any()
+            tid = [int.from_bytes(ids[i].tobytes(), "little") for i in range(n)]
+            order = sorted(range(n), key=lambda i: tid[i])                      # main.rs:93
+            proofs = [W.ClientProofTag(tid[i], tags[i].tobytes()) for i in order]
+            views.append((tid, proofs, vdaf))
+            views[-1] = (tid, proofs, vdaf.out_shares())
+        bad_a, bad_b, rounds = W.general_binary_split_test(views[0][1], views[1][1], VK, len(bad), 16)
+        want_ids = {views[0][0][i] for i in bad}
+        assert bad_a == want_ids and bad_b == want_ids and rounds > 1
+        aggs = []
+        for reports, (tid, _, _) in zip((alice, bob), views):
+            vdaf.prepare_encoded_keys(VK, reports)
+            keep = np.array([tid[i] not in bad_a for i in range(n)], np.uint8)
+            aggs.append(vdaf.aggregate(keep))
+        total = W.Prio3.unshard(aggs)
+        assert total == [int(sum(int(meas[i][e]) for i in range(n) if i not in bad)) for e in range(16)]
+    finally:
+        vdaf.close()
+
+
+def test_device_pointer_path_and_large_batch_properties():
+    """Inputs resident in HBM (torch tensors own the memory), sub-batching, and size-independent
+    properties at a size the oracle is only sampled on: duplicated reports give identical tags,
+    the aggregate of t copies is t times the aggregate of one (linearity), keep = 0 gives zero."""
+    import torch
+    p = W.Prio3Params(W.SUMVEC, 16, 128, 64)
+    op = O.params(W.SUMVEC, 16, 128, 64)
+    k, reps = 64, 40
+    lr, hr, _ = make_reports(p, k, seed=3)
+    alice, _ = server_views(lr, hr)
+    blob1, off1 = blob_of(alice)
+    blob = np.tile(blob1, reps)
+    offsets = np.concatenate([off1[:-1] + np.uint64(r * int(off1[-1])) for r in range(reps)] + [np.array([reps * int(off1[-1])], np.uint64)])
+    n = k * reps
+    dev = torch.device("cuda:0")
+    d_blob = torch.from_numpy(blob.copy()).to(dev)
+    d_off = torch.from_numpy(offsets.astype(np.int64)).to(dev)
+    d_tags = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+    d_ids = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+    d_status = torch.full((n,), -99, dtype=torch.int32, device=dev)
+    d_agg = torch.zeros(16 * p.output_len, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    vdaf = W.Prio3(p)
+    try:
+        vdaf.prepare_batch_dev(VK, d_blob.data_ptr(), d_off.data_ptr(), n, d_tags.data_ptr(), d_ids.data_ptr(), d_status.data_ptr())
+        vdaf.aggregate_dev(None, d_agg.data_ptr())
+        vdaf.synchronize()
+        tags = d_tags.cpu().numpy().reshape(n, 16)
+        assert not d_status.cpu().numpy().any()
+        o_tags, o_ids, o_status, o_outs = O.prio3_prepare_batch(op, VK, blob1, off1, nthreads=8)
+        for r in range(reps):
+            assert np.array_equal(tags[r * k:(r + 1) * k], o_tags)
+        assert np.array_equal(d_ids.cpu().numpy().reshape(n, 16)[:k], o_ids)
+        one = O.prio3_aggregate(o_outs, p.output_len)
+        want = b"".join(O.f_enc(O.f_dec(one[16 * e:16 * e + 16].tobytes()) * reps) for e in range(p.output_len))
+        assert d_agg.cpu().numpy().tobytes() == want
+        d_keep = torch.zeros(n, dtype=torch.uint8, device=dev)
+        vdaf.aggregate_dev(d_keep.data_ptr(), d_agg.data_ptr())
+        vdaf.synchronize()
+        assert not d_agg.cpu().numpy().any()
+    finally:
+        vdaf.close()
+
+
+def test_sum_rows_and_hh_bucket_sum():
+    import torch
+    dev = torch.device("cuda:0")
+    vdaf = W.new_sum_vec_256(2, 2, 5, 3)
+    try:
+        rng = np.random.default_rng(5)
+        # partial aggregates of 8 GPUs, output_len 1024 (the all-gather + mod-p reduce step)
+        rows = np.frombuffer(b"".join(O.f_enc(int.from_bytes(rng.bytes(16), "little")) for _ in range(8 * 1024)), np.uint8).reshape(8, -1)
+        d_rows = torch.from_numpy(rows.copy()).to(dev)
+        d_out = torch.zeros(16 * 1024, dtype=torch.uint8, device=dev)
+        vdaf.sum_rows_dev(d_rows.data_ptr(), 8, 1024, None, d_out.data_ptr())
+        vdaf.synchronize()
+        assert np.array_equal(d_out.cpu().numpy(), O.prio3_aggregate(rows, 1024))
+        # heavy hitters: (reps folded into n) clients x 512 buckets x 258 u32, bad clients skipped
+        for n, nb in ((37, 512), (5, 3), (300, 64)):
+            words = nb * 258
+            buckets = rng.integers(0, 2**32, size=(n, words), dtype=np.uint32)
+            keep = (rng.random(n) > 0.2).astype(np.uint8)
+            d_b = torch.from_numpy(buckets.view(np.int32)).to(dev)
+            d_k = torch.from_numpy(keep).to(dev)
+            d_acc = torch.zeros(words, dtype=torch.int32, device=dev)
+            for kp, dk in ((keep, d_k.data_ptr()), (None, None)):
+                vdaf.hh_bucket_sum_u32_dev(d_b.data_ptr(), dk, n, words, d_acc.data_ptr())
+                vdaf.synchronize()
+                assert np.array_equal(d_acc.cpu().numpy().view(np.uint32), O.hh_bucket_sum_u32(buckets, kp))
+    finally:
+        vdaf.close()

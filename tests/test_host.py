@@ -1,0 +1,85 @@
+"""CPU-side tests: the C-ABI library loads and exports every declared symbol, the CPU client
+agrees with the oracle's sharder byte for byte, and the host group-testing mirror behaves as the
+reference's own test expects (common/src/grouptest.rs:373-447)."""
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import whisper_amd as W
+from common import make_reports, det
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "whisper_gfx950.h")).read()
+    names = set(re.findall(r"\b(wh_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 17
+    for n in names:
+        assert hasattr(W.lib, n), n
+    # nothing under whisper_amd/ refers to the oracle
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "whisper_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "liboracle" not in src and "oracle_lib" not in src and "wh_oracle" not in src, f
+
+
+def test_sizes_match_oracle():
+    for circ, bits, ln, ch in [(0, 16, 128, 64), (0, 16, 1024, 128), (0, 2, 5, 3), (1, 0, 128, 64), (1, 0, 11, 3), (2, 64, 0, 0)]:
+        p = W.Prio3Params(circ, bits, ln, ch)
+        s = O.sizes(O.params(circ, bits, ln, ch))
+        for f in ("input_len", "proof_len", "verifier_len", "output_len", "joint_rand_len", "calls", "m", "arity",
+                  "leader_report_len", "helper_report_len"):
+            assert getattr(p.sizes, f) == getattr(s, f), f
+    assert W.Prio3Params(0, 16, 128, 64).sizes.leader_report_len == 45225
+    assert W.Prio3Params(0, 16, 128, 64).sizes.helper_report_len == 4345
+    with pytest.raises(W.WhError):
+        W.Prio3Params(0, 16, 0, 4)
+    with pytest.raises(W.WhError):
+        W.Prio3Params(0, 16, 4, 4, num_aggregators=3)
+
+
+@pytest.mark.parametrize("circ,bits,ln,ch", [(0, 2, 5, 3), (0, 16, 3, 7), (0, 16, 16, 8), (1, 0, 4, 2), (1, 0, 11, 3), (2, 64, 0, 0), (2, 8, 0, 0)])
+def test_client_matches_oracle_sharder(circ, bits, ln, ch):
+    p = W.Prio3Params(circ, bits, ln, ch)
+    op = O.params(circ, bits, ln, ch)
+    lr, hr, meas = make_reports(p, 3, seed=5, first_client_id=2**40 + 3, nthreads=2)
+    nonces = det(b"nonce5", 48).reshape(3, 16)
+    rands = det(b"rand5", 432).reshape(3, 144)
+    for i in range(3):
+        l2, h2 = O.prio3_shard_batched(op, [int(x) for x in meas[i]], nonces[i].tobytes(), rands[i].tobytes(), 2**40 + 3 + i)
+        assert lr[i].tobytes() == l2
+        assert hr[i].tobytes() == h2
+
+
+def test_group_testing_mirror():
+    # same scenario as grouptest.rs:373-447: 300 tags, 3 corrupted and 2 deleted on Bob's side
+    rnd = random.Random(7)
+    ids = sorted(rnd.getrandbits(128) for _ in range(300))
+    tags0 = [str(i).encode() for i in range(300)]
+    tags1 = list(tags0)
+    for i in (20, 68, 100):
+        tags1[i] = b"INCONSISTENCY"
+    p0 = [W.ClientProofTag(i, t) for i, t in zip(ids, tags0)]
+    p1 = [W.ClientProofTag(i, t) for i, t in zip(ids, tags1)]
+    for i in (200, 4):
+        del p1[i]
+    for size in (32, 16):
+        bad0, bad1, rounds = W.general_binary_split_test(p0, p1, bytes([1] * 16), 5, size)
+        assert len(bad0) == 5 and len(bad1) == 3
+        assert bad1 == {ids[20], ids[68], ids[100]}
+        assert bad0 == bad1 | {ids[200], ids[4]}
+    assert W.general_binary_split_test(p0, p0, bytes(16), 5, 16) == (set(), set(), 1)
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(W.WhError):
+        W.new_sum_vec_256(2, 16, 8, 4)

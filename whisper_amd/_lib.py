@@ -1,0 +1,62 @@
+"""ctypes binding of libwhisper_gfx950.so (include/whisper_gfx950.h)."""
+import ctypes as C
+import os
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwhisper_gfx950.so")
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make -C whisper_amd/csrc` (or __graft_entry__.build()); "
+        "there is no CPU fallback for the GPU path")
+lib = C.CDLL(LIB_PATH)
+
+
+class WhError(RuntimeError):
+    def __init__(self, code, what=""):
+        super().__init__(f"whisper_gfx950 error {code} {what}")
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("circuit", C.c_uint32), ("bits", C.c_uint32), ("len", C.c_uint32), ("chunk", C.c_uint32),
+                ("num_aggregators", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class Sizes(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in (
+        "input_len", "proof_len", "verifier_len", "output_len", "joint_rand_len", "calls", "m", "arity",
+        "leader_report_len", "helper_report_len")]
+
+
+EXPORTS = [
+    "wh_ctx_create", "wh_ctx_destroy", "wh_prio3_sizes_of", "wh_last_error", "wh_ctx_stream",
+    "wh_prio3_prepare_batch_dev", "wh_prio3_prepare_batch", "wh_prio3_out_shares",
+    "wh_prio3_aggregate_dev", "wh_prio3_aggregate", "wh_f128_sum_rows_dev", "wh_hh_bucket_sum_u32_dev",
+    "wh_ctx_synchronize", "wh_client_shard_batched", "wh_client_shard_many", "wh_test_f128_op",
+    "wh_test_xof_expand",
+]
+
+vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32
+lib.wh_ctx_create.argtypes = [i32, C.POINTER(Params), C.POINTER(vp)]
+lib.wh_ctx_destroy.argtypes = [vp]
+lib.wh_ctx_destroy.restype = None
+lib.wh_prio3_sizes_of.argtypes = [C.POINTER(Params), C.POINTER(Sizes)]
+lib.wh_last_error.argtypes = [vp]
+lib.wh_last_error.restype = C.c_char_p
+lib.wh_ctx_stream.argtypes = [vp]
+lib.wh_ctx_stream.restype = vp
+lib.wh_prio3_prepare_batch_dev.argtypes = [vp, vp, vp, vp, u64, vp, vp, vp]
+lib.wh_prio3_prepare_batch.argtypes = [vp, vp, vp, vp, u64, vp, vp, vp]
+lib.wh_prio3_out_shares.argtypes = [vp, vp]
+lib.wh_prio3_aggregate_dev.argtypes = [vp, vp, vp]
+lib.wh_prio3_aggregate.argtypes = [vp, vp, vp]
+lib.wh_f128_sum_rows_dev.argtypes = [vp, vp, u64, u32, vp, vp]
+lib.wh_hh_bucket_sum_u32_dev.argtypes = [vp, vp, vp, u64, u64, vp]
+lib.wh_ctx_synchronize.argtypes = [vp]
+lib.wh_client_shard_batched.argtypes = [C.POINTER(Params), vp, vp, vp, vp, vp, vp]
+lib.wh_client_shard_many.argtypes = [C.POINTER(Params), vp, u32, vp, vp, u64, u64, u32, vp, vp]
+lib.wh_test_f128_op.argtypes = [vp, i32, vp, vp, vp, u64]
+lib.wh_test_xof_expand.argtypes = [vp, vp, u64, u32, u32, vp, u32, u32, vp]
+for _n in EXPORTS:
+    getattr(lib, _n)  # AttributeError here = the library does not export what the header declares
+    if _n not in ("wh_ctx_destroy", "wh_last_error", "wh_ctx_stream"):
+        getattr(lib, _n).restype = i32

@@ -1,0 +1,382 @@
+// C-ABI layer of libwhisper_gfx950.so (include/whisper_gfx950.h): context, HBM workspace,
+// constant tables and kernel launches.  One context = one GPU = one HIP stream.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "host_math.hpp"
+#include "kernels.hip"
+
+using namespace wh;
+
+struct wh_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    wh_prio3_params params{};
+    HostSizes z{};
+    Prio3Dev P{};
+    Workspace W{};
+    uint64_t cap = 0;            // reports the workspace holds (one sub-batch)
+    // buffers owned by the context
+    F128 *d_omega = nullptr, *d_stab = nullptr;
+    uint8_t *d_aes = nullptr;    // 176 B round keys + 256 B sbox
+    uint8_t d_aes_key[16] = {0};
+    bool aes_valid = false;
+    F128 *d_out_shares = nullptr;  // [out_cap][output_len]
+    uint64_t out_cap = 0, n_last = 0;
+    int32_t *d_status_last = nullptr;  // status of the last batch (device, caller-owned or ours)
+    int32_t *d_status_own = nullptr; uint64_t status_cap = 0;
+    uint8_t *d_keep_eff = nullptr; uint64_t keep_cap = 0;
+    F128 *d_partials = nullptr; uint64_t partials_cap = 0;
+    // staging for the host-buffer entry points
+    uint8_t *d_blob = nullptr; uint64_t blob_cap = 0;
+    uint64_t *d_offsets = nullptr; uint64_t off_cap = 0;
+    uint8_t *d_tags = nullptr, *d_ids = nullptr; uint64_t tags_cap = 0, ids_cap = 0;
+    std::string err;
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                       \
+            return WH_ERR_HIP;                                                                    \
+        }                                                                                         \
+    } while (0)
+
+template <typename T>
+int32_t ensure(wh_ctx *c, T *&ptr, uint64_t &cap, uint64_t want) {
+    if (want <= cap && ptr) return WH_OK;
+    if (ptr) HIPCHK(c, hipFree(ptr));
+    ptr = nullptr; cap = 0;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&ptr), want * sizeof(T)));
+    cap = want;
+    return WH_OK;
+}
+
+void aes_tables(const uint8_t key[16], uint8_t out[432]) {
+    uint8_t *rk = out, *sbox = out + 176;
+    auto xt = [](uint8_t x) { return (uint8_t)((x << 1) ^ ((x >> 7) * 0x1b)); };
+    auto gm = [&](uint8_t a, uint8_t b) { uint8_t r = 0; while (b) { if (b & 1) r ^= a; a = xt(a); b >>= 1; } return r; };
+    for (int x = 0; x < 256; x++) {
+        uint8_t inv = 0;
+        if (x) for (int y = 1; y < 256; y++) if (gm((uint8_t)x, (uint8_t)y) == 1) { inv = (uint8_t)y; break; }
+        uint8_t s = inv, r = inv;
+        for (int i = 0; i < 4; i++) { r = (uint8_t)((r << 1) | (r >> 7)); s ^= r; }
+        sbox[x] = s ^ 0x63;
+    }
+    memcpy(rk, key, 16);
+    uint8_t rcon = 1;
+    for (int i = 16; i < 176; i += 4) {
+        uint8_t t[4] = {rk[i - 4], rk[i - 3], rk[i - 2], rk[i - 1]};
+        if (i % 16 == 0) {
+            uint8_t u = t[0];
+            t[0] = sbox[t[1]] ^ rcon; t[1] = sbox[t[2]]; t[2] = sbox[t[3]]; t[3] = sbox[u];
+            rcon = xt(rcon);
+        }
+        for (int k = 0; k < 4; k++) rk[i + k] = rk[i - 16 + k] ^ t[k];
+    }
+}
+
+// workspace for a sub-batch of `cap` reports
+int32_t alloc_workspace(wh_ctx *c, uint64_t cap) {
+    if (cap <= c->cap) return WH_OK;
+    Workspace &W = c->W;
+    void *ptrs[] = {W.desc, W.scal, W.weights, W.rlc, W.hrows, W.hlist, W.counters};
+    for (void *p : ptrs) if (p) HIPCHK(c, hipFree(p));
+    W = Workspace{};
+    c->cap = 0;
+    const HostSizes &z = c->z;
+    W.hrow_bytes = 16ull * (z.input_len + 2ull * z.proof_len);
+    HIPCHK(c, hipMalloc((void **)&W.desc, cap * sizeof(RepDesc)));
+    HIPCHK(c, hipMalloc((void **)&W.scal, cap * sizeof(RepScal)));
+    HIPCHK(c, hipMalloc((void **)&W.weights, cap * (uint64_t)(z.calls + 1) * sizeof(F128)));
+    HIPCHK(c, hipMalloc((void **)&W.rlc, cap * (uint64_t)(z.verifier_len + 5) * sizeof(F128)));
+    HIPCHK(c, hipMalloc((void **)&W.hrows, cap * W.hrow_bytes));
+    HIPCHK(c, hipMalloc((void **)&W.hlist, cap * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void **)&W.counters, 64));
+    c->cap = cap;
+    return WH_OK;
+}
+
+// sub-batch size: enough lanes to fill the chip several times over, bounded by HBM scratch
+uint64_t pick_cap(const wh_ctx *c, uint64_t n) {
+    const uint64_t hrow = 16ull * (c->z.input_len + 2ull * c->z.proof_len);
+    uint64_t by_mem = (24ull << 30) / (hrow + 4096);   // <= 24 GiB of expansion rows
+    uint64_t cap = 1ull << 19;
+    if (cap > by_mem) cap = by_mem;
+    if (cap > n) cap = n;
+    if (cap < 64) cap = 64;
+    return cap;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t wh_prio3_sizes_of(const wh_prio3_params *p, wh_prio3_sizes *out) {
+    HostSizes z;
+    if (!p || !out) return WH_ERR_PARAM;
+    int32_t rc = host_sizes(*p, z);
+    if (rc) return rc;
+    *out = wh_prio3_sizes{z.input_len, z.proof_len, z.verifier_len, z.output_len, z.jr_len,
+                          z.calls, z.m, z.arity, z.leader_len, z.helper_len};
+    return WH_OK;
+}
+
+int32_t wh_ctx_create(int32_t device_id, const wh_prio3_params *params, wh_ctx **out) {
+    if (!params || !out) return WH_ERR_PARAM;
+    *out = nullptr;
+    HostSizes z;
+    int32_t rc = host_sizes(*params, z);
+    if (rc) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return WH_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= ndev) return WH_ERR_NO_DEVICE;
+    wh_ctx *c = new wh_ctx();
+    c->device = device_id;
+    c->params = *params;
+    c->z = z;
+    auto fail = [&](int32_t code) { wh_ctx_destroy(c); return code; };
+    if (hipSetDevice(device_id) != hipSuccess) return fail(WH_ERR_HIP);
+    if (hipStreamCreate(&c->stream) != hipSuccess) return fail(WH_ERR_HIP);
+
+    // constant tables: w^j and s_i = sum_{j=1..calls} w^(ij)
+    std::vector<F128> omega(z.m), stab(z.gpoly_len);
+    F128 w = root_of_unity(z.log2m);
+    omega[0] = f_one();
+    for (uint32_t j = 1; j < z.m; j++) omega[j] = f_mul(omega[j - 1], w);
+    for (uint32_t i = 0; i < z.gpoly_len; i++) {
+        F128 acc = f_zero();
+        for (uint32_t j = 1; j <= z.calls; j++) acc = f_add(acc, omega[((uint64_t)i * j) % z.m]);
+        stab[i] = acc;
+    }
+    if (hipMalloc((void **)&c->d_omega, z.m * sizeof(F128)) != hipSuccess) return fail(WH_ERR_HIP);
+    if (hipMalloc((void **)&c->d_stab, z.gpoly_len * sizeof(F128)) != hipSuccess) return fail(WH_ERR_HIP);
+    if (hipMalloc((void **)&c->d_aes, 432) != hipSuccess) return fail(WH_ERR_HIP);
+    if (hipMemcpy(c->d_omega, omega.data(), z.m * sizeof(F128), hipMemcpyHostToDevice) != hipSuccess) return fail(WH_ERR_HIP);
+    if (hipMemcpy(c->d_stab, stab.data(), z.gpoly_len * sizeof(F128), hipMemcpyHostToDevice) != hipSuccess) return fail(WH_ERR_HIP);
+
+    Prio3Dev &P = c->P;
+    P.circuit = params->circuit; P.bits = params->bits; P.len = params->len; P.chunk = params->chunk;
+    P.input_len = z.input_len; P.proof_len = z.proof_len; P.verifier_len = z.verifier_len; P.output_len = z.output_len;
+    P.jr_len = z.jr_len; P.calls = z.calls; P.m = z.m; P.log2m = z.log2m; P.arity = z.arity; P.gpoly_len = z.gpoly_len;
+    P.alg_id = z.alg_id; P.leader_len = z.leader_len; P.helper_len = z.helper_len; P.n_weights = z.calls + 1;
+    P.half = f_inv(f_small(2));
+    P.m_inv = f_inv(f_small(z.m));
+    P.omega = c->d_omega; P.s_tab = c->d_stab;
+    *out = c;
+    return WH_OK;
+}
+
+void wh_ctx_destroy(wh_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    void *ptrs[] = {c->d_omega, c->d_stab, c->d_aes, c->d_out_shares, c->d_status_own, c->d_keep_eff, c->d_partials,
+                    c->d_blob, c->d_offsets, c->d_tags, c->d_ids, c->W.desc, c->W.scal, c->W.weights, c->W.rlc,
+                    c->W.hrows, c->W.hlist, c->W.counters};
+    for (void *p : ptrs) if (p) hipFree(p);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *wh_last_error(const wh_ctx *c) { return c ? c->err.c_str() : "null context"; }
+void *wh_ctx_stream(wh_ctx *c) { return c ? (void *)c->stream : nullptr; }
+int32_t wh_ctx_synchronize(wh_ctx *c) {
+    if (!c) return WH_ERR_PARAM;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return WH_OK;
+}
+
+int32_t wh_prio3_prepare_batch_dev(wh_ctx *c, const uint8_t verify_key[16], const uint8_t *d_blob,
+                                   const uint64_t *d_offsets, uint64_t n, uint8_t *d_tags, uint8_t *d_ids,
+                                   int32_t *d_status) {
+    if (!c || !verify_key || (n && (!d_blob || !d_offsets || !d_tags || !d_ids || !d_status))) return WH_ERR_PARAM;
+    if (c->params.circuit == WH_AVERAGE) return WH_ERR_UNSUPPORTED;
+    if (n > 0xfffffff0ull) return WH_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    const HostSizes &z = c->z;
+    int32_t rc;
+    // allocations first (none inside the launch sequence once the context is warm)
+    if ((rc = alloc_workspace(c, pick_cap(c, n)))) return rc;
+    if ((rc = ensure(c, c->d_out_shares, c->out_cap, (n ? n : 1) * (uint64_t)z.output_len))) return rc;
+    if (!c->aes_valid || memcmp(c->d_aes_key, verify_key, 16)) {
+        uint8_t t[432];
+        aes_tables(verify_key, t);
+        HIPCHK(c, hipMemcpyAsync(c->d_aes, t, 432, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        memcpy(c->d_aes_key, verify_key, 16);
+        c->aes_valid = true;
+    }
+    uint64_t vk0, vk1;
+    memcpy(&vk0, verify_key, 8); memcpy(&vk1, verify_key + 8, 8);
+    c->n_last = n;
+    c->d_status_last = d_status;
+    const size_t lds = 4 * 2 * (size_t)(z.calls + 1) * sizeof(F128);
+    for (uint64_t base = 0; base < n; base += c->cap) {
+        const uint32_t nb = (uint32_t)((n - base < c->cap) ? n - base : c->cap);
+        const uint32_t npad = (nb + 255) / 256 * 256;
+        HIPCHK(c, hipMemsetAsync(c->W.counters, 0, 64, c->stream));
+        hipLaunchKernelGGL(k_parse, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, d_blob, d_offsets + base, nb,
+                           d_status + base);
+        hipLaunchKernelGGL(k_expand, dim3(2 * npad / 256), dim3(256), 0, c->stream, c->P, c->W, npad);
+        hipLaunchKernelGGL(k_hash, dim3(2 * npad / 256), dim3(256), 0, c->stream, c->P, c->W, nb, npad, vk0, vk1,
+                           c->d_aes, d_ids + 16 * base, d_status + base);
+        hipLaunchKernelGGL(k_query_psum, dim3((nb + 3) / 4), dim3(256), lds, c->stream, c->P, c->W, nb,
+                           d_tags + 16 * base, reinterpret_cast<uint8_t *>(c->d_out_shares + base * z.output_len),
+                           d_status + base);
+        HIPCHK(c, hipGetLastError());
+    }
+    return WH_OK;
+}
+
+int32_t wh_prio3_prepare_batch(wh_ctx *c, const uint8_t verify_key[16], const uint8_t *blob, const uint64_t *offsets,
+                               uint64_t n, uint8_t *tags, uint8_t *ids, int32_t *status) {
+    if (!c || !verify_key || (n && (!blob || !offsets || !tags || !ids || !status))) return WH_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n == 0) { c->n_last = 0; return WH_OK; }
+    for (uint64_t i = 0; i < n; i++) if (offsets[i + 1] < offsets[i]) return WH_ERR_PARAM;
+    int32_t rc;
+    const uint64_t base0 = offsets[0], bytes = offsets[n] - base0;
+    if ((rc = ensure(c, c->d_blob, c->blob_cap, bytes + 64))) return rc;
+    if ((rc = ensure(c, c->d_offsets, c->off_cap, n + 1))) return rc;
+    if ((rc = ensure(c, c->d_tags, c->tags_cap, 16 * n))) return rc;
+    if ((rc = ensure(c, c->d_ids, c->ids_cap, 16 * n))) return rc;
+    if ((rc = ensure(c, c->d_status_own, c->status_cap, n))) return rc;
+    std::vector<uint64_t> rel(n + 1);
+    for (uint64_t i = 0; i <= n; i++) rel[i] = offsets[i] - base0;
+    HIPCHK(c, hipMemcpyAsync(c->d_blob, blob + base0, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_offsets, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((rc = wh_prio3_prepare_batch_dev(c, verify_key, c->d_blob, c->d_offsets, n, c->d_tags, c->d_ids, c->d_status_own)))
+        return rc;
+    HIPCHK(c, hipMemcpyAsync(tags, c->d_tags, 16 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(ids, c->d_ids, 16 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(status, c->d_status_own, 4 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return WH_OK;
+}
+
+int32_t wh_prio3_out_shares(wh_ctx *c, uint8_t *out) {
+    if (!c || !out) return WH_ERR_PARAM;
+    if (!c->n_last) return WH_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, c->d_out_shares, c->n_last * c->z.output_len * sizeof(F128), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return WH_OK;
+}
+
+// keep_eff[i] = keep[i] && status[i] == 0
+__global__ void k_keep_eff(const uint8_t *keep, const int32_t *status, uint64_t n, uint8_t *out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (status[i] == 0) && (!keep || keep[i]);
+}
+
+static int32_t sum_rows(wh_ctx *c, const F128 *rows, const uint8_t *d_keep, uint64_t n, uint32_t len, F128 *d_out) {
+    int32_t rc;
+    const uint32_t tpr = len < 256 ? len : 256, rstep = 256 / tpr;
+    // ~2048 blocks, each a slab of rows
+    uint64_t rpb = (n + 2047) / 2048;
+    if (rpb < rstep) rpb = rstep;
+    const uint32_t nblocks = (uint32_t)((n + rpb - 1) / rpb);
+    if (n == 0) { HIPCHK(c, hipMemsetAsync(d_out, 0, len * sizeof(F128), c->stream)); return WH_OK; }
+    if ((rc = ensure(c, c->d_partials, c->partials_cap, (uint64_t)nblocks * rstep * len))) return rc;
+    hipLaunchKernelGGL(k_agg_partial, dim3(nblocks), dim3(256), 0, c->stream, rows, d_keep, n, len, (uint32_t)rpb, c->d_partials);
+    hipLaunchKernelGGL(k_agg_final, dim3((len + 255) / 256), dim3(256), 0, c->stream, c->d_partials, nblocks * rstep, len, d_out);
+    HIPCHK(c, hipGetLastError());
+    return WH_OK;
+}
+
+int32_t wh_prio3_aggregate_dev(wh_ctx *c, const uint8_t *d_keep, uint8_t *d_agg) {
+    if (!c || !d_agg) return WH_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t n = c->n_last;
+    int32_t rc;
+    if (n) {
+        if (!c->d_status_last) return WH_ERR_STATE;
+        if ((rc = ensure(c, c->d_keep_eff, c->keep_cap, n))) return rc;
+        hipLaunchKernelGGL(k_keep_eff, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, d_keep, c->d_status_last, n, c->d_keep_eff);
+    }
+    return sum_rows(c, c->d_out_shares, c->d_keep_eff, n, c->z.output_len, reinterpret_cast<F128 *>(d_agg));
+}
+
+int32_t wh_prio3_aggregate(wh_ctx *c, const uint8_t *keep, uint8_t *agg) {
+    if (!c || !agg) return WH_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t n = c->n_last, len = c->z.output_len;
+    uint8_t *d_keep = nullptr, *d_agg = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_agg, len * 16));
+    if (keep && n) {
+        HIPCHK(c, hipMalloc((void **)&d_keep, n));
+        HIPCHK(c, hipMemcpyAsync(d_keep, keep, n, hipMemcpyHostToDevice, c->stream));
+    }
+    int32_t rc = wh_prio3_aggregate_dev(c, d_keep, d_agg);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(agg, d_agg, len * 16, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { c->err = hipGetErrorString(e); rc = WH_ERR_HIP; }
+    }
+    hipStreamSynchronize(c->stream);
+    if (d_keep) hipFree(d_keep);
+    hipFree(d_agg);
+    return rc;
+}
+
+int32_t wh_f128_sum_rows_dev(wh_ctx *c, const uint8_t *d_rows, uint64_t n_rows, uint32_t len, const uint8_t *d_keep,
+                             uint8_t *d_out) {
+    if (!c || !d_out || (n_rows && !d_rows) || !len) return WH_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    return sum_rows(c, reinterpret_cast<const F128 *>(d_rows), d_keep, n_rows, len, reinterpret_cast<F128 *>(d_out));
+}
+
+int32_t wh_hh_bucket_sum_u32_dev(wh_ctx *c, const uint32_t *d_buckets, const uint8_t *d_keep, uint64_t n, uint64_t words,
+                                 uint32_t *d_acc) {
+    if (!c || !d_acc || !words || (n && !d_buckets)) return WH_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(d_acc, 0, words * 4, c->stream));
+    if (!n) return WH_OK;
+    const uint32_t gx = (uint32_t)((words + 4 * 256 - 1) / (4 * 256));
+    // enough (x, y) blocks to fill the chip: target ~4096 blocks
+    uint32_t gy = 4096 / gx; if (gy < 1) gy = 1; if (gy > n) gy = (uint32_t)n; if (gy > 65535) gy = 65535;
+    const uint32_t cpb = (uint32_t)((n + gy - 1) / gy);
+    gy = (uint32_t)((n + cpb - 1) / cpb);
+    hipLaunchKernelGGL(k_hh_sum_u32, dim3(gx, gy), dim3(256), 0, c->stream, d_buckets, d_keep, n, words, cpb, d_acc);
+    HIPCHK(c, hipGetLastError());
+    return WH_OK;
+}
+
+int32_t wh_test_f128_op(wh_ctx *c, int32_t op, const uint8_t *a, const uint8_t *b, uint8_t *out, uint64_t n) {
+    if (!c || !a || !out || !n) return WH_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    F128 *da, *db, *dout;
+    HIPCHK(c, hipMalloc((void **)&da, 16 * n)); HIPCHK(c, hipMalloc((void **)&db, 16 * n)); HIPCHK(c, hipMalloc((void **)&dout, 16 * n));
+    HIPCHK(c, hipMemcpy(da, a, 16 * n, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(db, b ? b : a, 16 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_test_f128, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, da, db, dout, (uint32_t)n, op);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, dout, 16 * n, hipMemcpyDeviceToHost));
+    hipFree(da); hipFree(db); hipFree(dout);
+    return WH_OK;
+}
+
+int32_t wh_test_xof_expand(wh_ctx *c, const uint8_t *seeds, uint64_t n, uint32_t alg_id, uint32_t usage, const uint8_t *binder,
+                           uint32_t binder_len, uint32_t n_elems, uint8_t *out) {
+    if (!c || !seeds || !out || !n || !n_elems) return WH_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint8_t *ds, *db, *dout;
+    HIPCHK(c, hipMalloc((void **)&ds, 16 * n)); HIPCHK(c, hipMalloc((void **)&db, binder_len + 16));
+    HIPCHK(c, hipMalloc((void **)&dout, 16ull * n_elems * n));
+    HIPCHK(c, hipMemcpy(ds, seeds, 16 * n, hipMemcpyHostToDevice));
+    if (binder_len) HIPCHK(c, hipMemcpy(db, binder, binder_len, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_test_xof, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, c->stream, ds, alg_id, usage, db, binder_len, n_elems, dout, (uint32_t)n);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, dout, 16ull * n_elems * n, hipMemcpyDeviceToHost));
+    hipFree(ds); hipFree(db); hipFree(dout);
+    return WH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,224 @@
+// SHAKE128 sponge for gfx950 device code (one sponge per lane, state in VGPRs) and host code.
+//
+// Reference behaviour being replaced: XofShake128 (batched-flpcp-rs/src/vdaf/xof.rs:197-218,
+// sha3 0.10.8 crate) and the rejection sampler Prng::get (prng.rs:73-99).
+//
+// Layout decisions for CDNA4:
+//  * the 25-lane state lives in 50 VGPRs per work-item; every state index is a compile-time
+//    constant (runtime-indexed register arrays would go to scratch memory);
+//  * the hot absorb path takes a whole 168-byte rate block from memory as twenty-one 8-byte
+//    loads at any byte alignment (gfx950 global loads are byte-addressable), XORs it in with
+//    static indices and permutes;
+//  * partial blocks (prefixes, segment seams, tails) take a slow path that selects the state
+//    word with a wave-uniform switch (the position is the same in every lane of a wave because
+//    a launch only mixes reports of one shape).
+#pragma once
+#include "f128.hpp"
+
+namespace wh {
+
+constexpr unsigned SHAKE128_RATE = 168;
+constexpr unsigned RATE_WORDS = 21;
+
+#if defined(__HIPCC__)
+__device__ __constant__ const uint64_t KECCAK_RC_DEV[24] = {
+    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+    0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+    0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+    0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+    0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+    0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+#endif
+static const uint64_t KECCAK_RC_HOST[24] = {
+    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+    0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+    0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+    0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+    0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+    0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+
+WH_HD uint64_t rotl64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
+
+// One Keccak-f[1600] round, all indices static.
+#define WH_KECCAK_ROUND(a, rc)                                                                   \
+    do {                                                                                         \
+        uint64_t c0 = a[0] ^ a[5] ^ a[10] ^ a[15] ^ a[20];                                       \
+        uint64_t c1 = a[1] ^ a[6] ^ a[11] ^ a[16] ^ a[21];                                       \
+        uint64_t c2 = a[2] ^ a[7] ^ a[12] ^ a[17] ^ a[22];                                       \
+        uint64_t c3 = a[3] ^ a[8] ^ a[13] ^ a[18] ^ a[23];                                       \
+        uint64_t c4 = a[4] ^ a[9] ^ a[14] ^ a[19] ^ a[24];                                       \
+        uint64_t d0 = c4 ^ rotl64(c1, 1), d1 = c0 ^ rotl64(c2, 1), d2 = c1 ^ rotl64(c3, 1);      \
+        uint64_t d3 = c2 ^ rotl64(c4, 1), d4 = c3 ^ rotl64(c0, 1);                               \
+        uint64_t b0 = a[0] ^ d0;                                                                 \
+        uint64_t b1 = rotl64(a[6] ^ d1, 44), b2 = rotl64(a[12] ^ d2, 43);                        \
+        uint64_t b3 = rotl64(a[18] ^ d3, 21), b4 = rotl64(a[24] ^ d4, 14);                       \
+        uint64_t b5 = rotl64(a[3] ^ d3, 28), b6 = rotl64(a[9] ^ d4, 20);                         \
+        uint64_t b7 = rotl64(a[10] ^ d0, 3), b8 = rotl64(a[16] ^ d1, 45);                        \
+        uint64_t b9 = rotl64(a[22] ^ d2, 61);                                                    \
+        uint64_t b10 = rotl64(a[1] ^ d1, 1), b11 = rotl64(a[7] ^ d2, 6);                         \
+        uint64_t b12 = rotl64(a[13] ^ d3, 25), b13 = rotl64(a[19] ^ d4, 8);                      \
+        uint64_t b14 = rotl64(a[20] ^ d0, 18);                                                   \
+        uint64_t b15 = rotl64(a[4] ^ d4, 27), b16 = rotl64(a[5] ^ d0, 36);                       \
+        uint64_t b17 = rotl64(a[11] ^ d1, 10), b18 = rotl64(a[17] ^ d2, 15);                     \
+        uint64_t b19 = rotl64(a[23] ^ d3, 56);                                                   \
+        uint64_t b20 = rotl64(a[2] ^ d2, 62), b21 = rotl64(a[8] ^ d3, 55);                       \
+        uint64_t b22 = rotl64(a[14] ^ d4, 39), b23 = rotl64(a[15] ^ d0, 41);                     \
+        uint64_t b24 = rotl64(a[21] ^ d1, 2);                                                    \
+        a[0] = b0 ^ (~b1 & b2) ^ (rc);                                                           \
+        a[1] = b1 ^ (~b2 & b3); a[2] = b2 ^ (~b3 & b4); a[3] = b3 ^ (~b4 & b0); a[4] = b4 ^ (~b0 & b1); \
+        a[5] = b5 ^ (~b6 & b7); a[6] = b6 ^ (~b7 & b8); a[7] = b7 ^ (~b8 & b9); a[8] = b8 ^ (~b9 & b5); a[9] = b9 ^ (~b5 & b6); \
+        a[10] = b10 ^ (~b11 & b12); a[11] = b11 ^ (~b12 & b13); a[12] = b12 ^ (~b13 & b14); a[13] = b13 ^ (~b14 & b10); a[14] = b14 ^ (~b10 & b11); \
+        a[15] = b15 ^ (~b16 & b17); a[16] = b16 ^ (~b17 & b18); a[17] = b17 ^ (~b18 & b19); a[18] = b18 ^ (~b19 & b15); a[19] = b19 ^ (~b15 & b16); \
+        a[20] = b20 ^ (~b21 & b22); a[21] = b21 ^ (~b22 & b23); a[22] = b22 ^ (~b23 & b24); a[23] = b23 ^ (~b24 & b20); a[24] = b24 ^ (~b20 & b21); \
+    } while (0)
+
+WH_HD void keccak_f1600(uint64_t (&a)[25]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+    for (int r = 0; r < 24; r++) WH_KECCAK_ROUND(a, KECCAK_RC_DEV[r]);
+#else
+    for (int r = 0; r < 24; r++) WH_KECCAK_ROUND(a, KECCAK_RC_HOST[r]);
+#endif
+}
+
+// unaligned little-endian loads/stores (byte-addressable on gfx950 and on x86)
+WH_HD uint64_t ld64(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+WH_HD F128 ld128(const uint8_t *p) { F128 v; __builtin_memcpy(&v, p, 16); return v; }
+WH_HD void st128(uint8_t *p, const F128 &v) { __builtin_memcpy(p, &v, 16); }
+
+struct Sponge {
+    uint64_t st[25];
+    uint32_t pos;  // bytes absorbed into (or squeezed from) the current rate block
+
+    WH_HD void reset() {
+#pragma unroll
+        for (int i = 0; i < 25; i++) st[i] = 0;
+        pos = 0;
+    }
+
+    // st[idx] ^= w with idx only known at run time.  On the device idx is wave-uniform; the
+    // readfirstlane makes the switch a scalar branch tree instead of 21 exec-masked bodies.
+    WH_HD void xor_word(uint32_t idx, uint64_t w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        idx = __builtin_amdgcn_readfirstlane(idx);
+#endif
+        switch (idx) {
+#define C_(i) case i: st[i] ^= w; break;
+            C_(0) C_(1) C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8) C_(9) C_(10)
+            C_(11) C_(12) C_(13) C_(14) C_(15) C_(16) C_(17) C_(18) C_(19) C_(20)
+#undef C_
+        }
+    }
+    WH_HD uint64_t get_word(uint32_t idx) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        idx = __builtin_amdgcn_readfirstlane(idx);
+#endif
+        switch (idx) {
+#define C_(i) case i: return st[i];
+            C_(0) C_(1) C_(2) C_(3) C_(4) C_(5) C_(6) C_(7) C_(8) C_(9) C_(10)
+            C_(11) C_(12) C_(13) C_(14) C_(15) C_(16) C_(17) C_(18) C_(19) C_(20)
+#undef C_
+        }
+        return 0;
+    }
+
+    WH_HD void absorb_byte(uint8_t b) {
+        xor_word(pos >> 3, (uint64_t)b << (8 * (pos & 7)));
+        if (++pos == SHAKE128_RATE) { keccak_f1600(st); pos = 0; }
+    }
+
+    // XofShake128::init (xof.rs:200-209): [len(dst)=8] || dst || seed, 25 bytes, written
+    // straight into the zero state.  dst = {7, 0, id_be32, usage_be16} (vdaf.rs:339-346).
+    // The seed is passed as its two little-endian words.
+    WH_HD void init_xof(uint32_t alg_id, uint32_t usage, uint64_t s0, uint64_t s1) {
+        reset();
+        uint64_t w0 = 8ull | (7ull << 8) | (0ull << 16) | ((uint64_t)((alg_id >> 24) & 0xff) << 24) |
+                      ((uint64_t)((alg_id >> 16) & 0xff) << 32) | ((uint64_t)((alg_id >> 8) & 0xff) << 40) |
+                      ((uint64_t)(alg_id & 0xff) << 48) | ((uint64_t)((usage >> 8) & 0xff) << 56);
+        st[0] = w0;
+        st[1] = (uint64_t)(usage & 0xff) | (s0 << 8);
+        st[2] = (s0 >> 56) | (s1 << 8);
+        st[3] = s1 >> 56;
+        pos = 25;
+    }
+    WH_HD void init_xof(uint32_t alg_id, uint32_t usage, const uint8_t *seed16) {
+        init_xof(alg_id, usage, ld64(seed16), ld64(seed16 + 8));
+    }
+
+    // absorb the 8 bytes of w (little endian) at any position inside the block
+    WH_HD void absorb_u64(uint64_t w) {
+        if (pos + 8 <= SHAKE128_RATE) {
+            uint32_t sh = (pos & 7) * 8, idx = pos >> 3;
+            xor_word(idx, w << sh);
+            if (sh) xor_word(idx + 1, w >> (64 - sh));
+            pos += 8;
+            if (pos == SHAKE128_RATE) { keccak_f1600(st); pos = 0; }
+        } else {
+#pragma unroll 1
+            for (int i = 0; i < 8; i++) absorb_byte((uint8_t)(w >> (8 * i)));
+        }
+    }
+    WH_HD void absorb_f(const F128 &v) { absorb_u64(v.lo); absorb_u64(v.hi); }
+
+    // absorb `len` bytes at `p` (any alignment).  Whole rate blocks take the static-index
+    // path; the stretch before the first block boundary and the tail take the word/byte path.
+    WH_HD void absorb(const uint8_t *p, uint32_t len) {
+        for (;;) {
+            if (pos == 0) {
+                while (len >= SHAKE128_RATE) {
+#pragma unroll
+                    for (int i = 0; i < (int)RATE_WORDS; i++) st[i] ^= ld64(p + 8 * i);
+                    keccak_f1600(st);
+                    p += SHAKE128_RATE;
+                    len -= SHAKE128_RATE;
+                }
+            }
+            if (!len) break;
+            if (len >= 8 && pos + 8 <= SHAKE128_RATE) {
+                absorb_u64(ld64(p));
+                p += 8; len -= 8;
+            } else {
+                absorb_byte(*p++);
+                len--;
+            }
+        }
+    }
+
+    // SHAKE128 padding (0x1f ... 0x80) and the permutation that yields the first output block
+    WH_HD void finalize() {
+        xor_word(pos >> 3, (uint64_t)0x1f << (8 * (pos & 7)));
+        st[20] ^= 0x8000000000000000ULL;
+        keccak_f1600(st);
+        pos = 0;
+    }
+    // Xof::into_seed (xof.rs:127-132): first 16 output bytes
+    WH_HD F128 into_seed() { finalize(); return F128{st[0], st[1]}; }
+};
+
+// Prng::get over a finalized sponge (prng.rs:73-99): consecutive 16-byte chunks of the output
+// stream, little endian, chunks >= p skipped; writes `n` elements (16 B each) at `out`.
+// Two rate blocks hold exactly 21 chunks, so the loop below is the whole stream walk.
+WH_HD void xof_emit(Sponge &s, uint8_t *out, uint32_t n) {
+    uint32_t left = n;
+#define WH_EMIT(lo_, hi_)                                                                      \
+    do {                                                                                         \
+        uint64_t l_ = (lo_), h_ = (hi_);                                                         \
+        if (left && f_in_range(l_, h_)) { st128(out, F128{l_, h_}); out += 16; left--; }         \
+    } while (0)
+    for (;;) {
+        // even block: chunks (0,1) .. (18,19); word 20 is the low half of a straddling chunk
+#pragma unroll
+        for (int i = 0; i < 10; i++) WH_EMIT(s.st[2 * i], s.st[2 * i + 1]);
+        if (!left) break;
+        uint64_t carry = s.st[20];
+        keccak_f1600(s.st);
+        WH_EMIT(carry, s.st[0]);
+#pragma unroll
+        for (int i = 0; i < 10; i++) WH_EMIT(s.st[2 * i + 1], s.st[2 * i + 2]);
+        if (!left) break;
+        keccak_f1600(s.st);
+    }
+#undef WH_EMIT
+}
+
+}  // namespace wh

@@ -1,0 +1,502 @@
+// gfx950 kernels for whisper's server hot path: batched FLPCP verification of Prio3 reports
+// (reference: Prio3::prepare_batched, batched-flpcp-rs/src/vdaf/prio3.rs:2466-2879, called from
+// server-batch-prio3/src/main.rs:33-60) and share aggregation (vdaf.rs:658-676,
+// hhcore/src/bucket.rs:48-55).
+//
+// Pipeline over one sub-batch of encoded reports resident in HBM:
+//   parse   (lane / report)   header checks, pointers, Helper compaction
+//   expand  (lane / Helper)   SHAKE128 expansion of the Helper's seeds into share rows
+//   hash    (lane / report)   joint-rand + query-rand Fiat-Shamir sponges, barycentric weights;
+//                             public-parts hash, RLC stream, AES testing id
+//   query   (wave / report)   range checks, truncate, wire evaluation at r, decide, RLC tag
+// then, once the host has the group-test verdict:
+//   aggregate                 masked column sums of the out shares (HBM streaming)
+//
+// The SHAKE work is one sponge per lane with the state in VGPRs (keccak.hpp); the field work
+// is one wavefront per report with lanes across the gadget chunk (f128.hpp).  No MFMA: this is
+// prime-field integer arithmetic.
+#include <hip/hip_runtime.h>
+#include "keccak.hpp"
+#include "prio3_dev.hpp"
+
+namespace wh {
+
+// ------------------------------------------------------------------------------- helpers ----
+__device__ __forceinline__ uint64_t be64(const uint8_t *p) { return __builtin_bswap64(ld64(p)); }
+
+__device__ __forceinline__ F128 shfl_xor_f(const F128 &v, int mask) {
+    F128 r;
+    r.lo = __shfl_xor((unsigned long long)v.lo, mask, 64);
+    r.hi = __shfl_xor((unsigned long long)v.hi, mask, 64);
+    return r;
+}
+// sum over the 64 lanes of a wavefront, result in every lane
+__device__ __forceinline__ F128 wave_sum(F128 v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = f_add(v, shfl_xor_f(v, m));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v |= __shfl_xor(v, m, 64);
+    return v;
+}
+// x^e for a small per-lane exponent
+__device__ __forceinline__ F128 f_pow_u32(F128 x, uint32_t e) {
+    F128 r = f_one();
+    while (e) {
+        if (e & 1) r = f_mul(r, x);
+        e >>= 1;
+        if (e) x = f_sqr(x);
+    }
+    return r;
+}
+
+// --------------------------------------------------------------------------------- parse ----
+// VdafBatchedKey::decode_with_param (vdaf.rs:164-192) as far as structure goes: lengths,
+// agg_id, num_queries.  Field-element range checks happen where the elements are loaded
+// (query kernel).  Trailing bytes are not looked at (server-batch-prio3/src/main.rs:46-47).
+__global__ void k_parse(Prio3Dev P, Workspace W, const uint8_t *blob, const uint64_t *offsets, uint32_t n,
+                        int32_t *status) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *rep = blob + offsets[i];
+    uint64_t rep_len = offsets[i + 1] - offsets[i];
+    RepDesc d;
+    d.base = rep; d.meas = d.proof1 = d.proof2 = d.tail = d.jr_blind = nullptr; d.role = 0; d.hslot = 0;
+    int32_t st = ST_OK;
+    if (rep_len < 49) st = ST_ERR_SHORT;
+    if (!st) {
+        d.role = rep[48];
+        if (d.role >= 2) st = ST_ERR_AGG_ID;
+    }
+    if (!st) {
+        uint64_t share_len = d.role == 0 ? 16ull * (P.input_len + 2ull * P.proof_len) + 16 : 64;
+        uint64_t off = 49 + share_len;
+        if (rep_len < off + 40) st = ST_ERR_SHORT;
+        if (!st) {
+            d.tail = rep + off;
+            uint64_t nq = be64(rep + off + 32);
+            uint64_t rest = rep_len - (off + 40);
+            if (nq != P.verifier_len) {
+                st = (nq > rest / 32 || rest - 32 * nq < 32) ? ST_ERR_SHORT : ST_ERR_NUM_QUERIES;
+            } else if (rest < 32ull * P.verifier_len + 32) {
+                st = ST_ERR_SHORT;
+            }
+        }
+    }
+    if (!st) {
+        if (d.role == 0) {
+            d.meas = rep + 49;
+            d.proof1 = d.meas + 16ull * P.input_len;
+            d.jr_blind = d.proof1 + 16ull * P.proof_len;
+            d.proof2 = d.jr_blind + 16;
+        } else {
+            d.hslot = atomicAdd(&W.counters[0], 1u);
+            W.hlist[d.hslot] = i;
+            uint8_t *row = W.hrows + (uint64_t)d.hslot * W.hrow_bytes;
+            d.meas = row;
+            d.proof1 = row + 16ull * P.input_len;
+            d.proof2 = d.proof1 + 16ull * P.proof_len;
+            d.jr_blind = rep + 49 + 32;
+        }
+    }
+    W.desc[i] = d;
+    status[i] = st;
+}
+
+// -------------------------------------------------------------------------------- expand ----
+// Helper share expansion (prio3.rs:2480-2536): P::seed_stream(seed, dst(usage), [agg_id])
+// .into_field_vec(n).  Jobs [0, npad) expand the measurement share, jobs [npad, 2 npad) the two
+// proof shares, so a wave never mixes the two shapes.
+__global__ void __launch_bounds__(256) k_expand(Prio3Dev P, Workspace W, uint32_t npad) {
+    uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t nh = W.counters[0];
+    uint32_t which = job >= npad;
+    uint32_t slot = which ? job - npad : job;
+    if (slot >= nh) return;
+    const RepDesc d = W.desc[W.hlist[slot]];
+    const uint8_t *seeds = d.base + 49;  // meas_seed | proof1_seed | jr_blind | proof2_seed
+    uint8_t agg = (uint8_t)d.role;
+    Sponge s;
+    if (!which) {
+        s.init_xof(P.alg_id, DST_MEAS, seeds);
+        s.absorb_byte(agg);
+        s.finalize();
+        xof_emit(s, const_cast<uint8_t *>(d.meas), P.input_len);
+    } else {
+#pragma unroll 1
+        for (int t = 0; t < 2; t++) {
+            s.init_xof(P.alg_id, DST_PROOF, seeds + (t ? 48 : 16));
+            s.absorb_byte(agg);
+            s.finalize();
+            xof_emit(s, const_cast<uint8_t *>(t ? d.proof2 : d.proof1), P.proof_len);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- hash ----
+// derive_joint_rand_seed (prio3.rs:482-493) with this aggregator's own part substituted at
+// index `role` (prio3.rs:2564-2578, 2651-2665 -- the query-rand seed reuses DST_JR_SEED).
+__device__ __forceinline__ F128 derive_seed(const Prio3Dev &P, Sponge &s, const uint8_t *parts, uint32_t role,
+                                            const F128 &own) {
+    s.init_xof(P.alg_id, DST_JR_SEED, 0ull, 0ull);
+    if (role == 0) { s.absorb_f(own); s.absorb(parts + 16, 16); }
+    else { s.absorb(parts, 16); s.absorb_f(own); }
+    return s.into_seed();
+}
+
+// Job A (lanes [0, npad)): joint randomness, query randomness, barycentric weights.
+// Job B (lanes [npad, 2 npad)): public-parts hash, RLC coefficients, testing id.
+__global__ void __launch_bounds__(256) k_hash(Prio3Dev P, Workspace W, uint32_t n, uint32_t npad, uint64_t vk0,
+                                              uint64_t vk1, const uint8_t *aes_rk, uint8_t *testing_ids,
+                                              int32_t *status) {
+    uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t which = job >= npad;
+    uint32_t i = which ? job - npad : job;
+    if (i >= n || status[i] != ST_OK) return;
+    const RepDesc d = W.desc[i];
+    RepScal *sc = &W.scal[i];
+    const uint8_t *ps_parts = d.base + 16;
+    const uint8_t *ps2_parts = d.tail;
+    const uint8_t *pp = d.tail + 40;
+    const uint8_t *qr_blind = pp + 32ull * P.verifier_len;
+    const uint8_t *nonce = qr_blind + 16;
+    Sponge s;
+    if (!which) {
+        // own joint-rand part: XOF(blind, dst 7) . [agg_id] . nonce . enc(meas)   (prio3.rs:2543-2555)
+        s.init_xof(P.alg_id, DST_JR_PART, d.jr_blind);
+        s.absorb_byte((uint8_t)d.role);
+        s.absorb(nonce, 16);
+        s.absorb(d.meas, 16u * P.input_len);
+        F128 own_jr = s.into_seed();
+        sc->rand_diff[0] = !f_eq(own_jr, ld128(ps_parts + 16 * d.role));
+        F128 seed = derive_seed(P, s, ps_parts, d.role, own_jr);
+        uint32_t njr = 2 * P.jr_len;
+        s.init_xof(P.alg_id, DST_JOINT_RAND, seed.lo, seed.hi);
+        s.finalize();
+        xof_emit(s, reinterpret_cast<uint8_t *>(sc->jr), njr);
+        // own query-rand part: XOF(blind, dst 8) . enc(jr_fused) . enc(proof1) . enc(proof2)  (:2610-2642)
+        s.init_xof(P.alg_id, DST_QR_PART, qr_blind);
+        s.absorb(reinterpret_cast<const uint8_t *>(sc->jr), 16 * njr);
+        s.absorb(d.proof1, 16u * P.proof_len);
+        s.absorb(d.proof2, 16u * P.proof_len);
+        F128 own_qr = s.into_seed();
+        sc->rand_diff[1] = !f_eq(own_qr, ld128(ps2_parts + 16 * d.role));
+        seed = derive_seed(P, s, ps2_parts, d.role, own_qr);
+        s.init_xof(P.alg_id, DST_QUERY_RAND, seed.lo, seed.hi);
+        s.finalize();
+        xof_emit(s, reinterpret_cast<uint8_t *>(sc->qr), 2);
+
+        // flp.rs:413-419 for both runs: r^m == 1 is FlpError::Query
+        F128 r1 = sc->qr[0], r = sc->qr[1];
+        F128 r1m = f_sqr_n(r1, P.log2m), rm = f_sqr_n(r, P.log2m);
+        if (f_eq(r1m, f_one()) || f_eq(rm, f_one())) { status[i] = ST_ERR_QUERY_RAND; return; }
+        // Barycentric weights for run 2 (run 1's verifier never reaches the tag, prio3.rs:2713):
+        //   L_j(r) = (r^m - 1)/m * w^j / (r - w^j),  j = 0..calls,  w = omega_m.
+        // One inversion per report: prefix products of (r - w^j) are parked in the weight row.
+        F128 *L = W.weights + (uint64_t)i * P.n_weights;
+        F128 acc = f_one();
+        for (uint32_t j = 0; j < P.n_weights; j++) {
+            L[j] = acc;
+            acc = f_mul(acc, f_sub(r, P.omega[j]));
+        }
+        F128 inv = f_inv(acc);
+        F128 k = f_mul(f_sub(rm, f_one()), P.m_inv);
+        for (uint32_t j = P.n_weights; j-- > 0;) {
+            F128 w = P.omega[j];
+            F128 dinv = f_mul(inv, L[j]);          // 1 / (r - w^j)
+            inv = f_mul(inv, f_sub(r, w));
+            L[j] = f_mul(f_mul(k, w), dinv);
+        }
+    } else {
+        // hash of the public parts (prio3.rs:2808-2840): XOF(0, dst 10) . parts . parts2 . enc(pp0) . enc(pp1)
+        s.init_xof(P.alg_id, DST_HASH, 0ull, 0ull);
+        s.absorb(ps_parts, 32);
+        s.absorb(ps2_parts, 32);
+        s.absorb(pp, 32u * P.verifier_len);
+        F128 seed = s.into_seed();
+        s.init_xof(P.alg_id, DST_HASH, seed.lo, seed.hi);
+        s.finalize();
+        xof_emit(s, reinterpret_cast<uint8_t *>(&sc->hash), 1);
+        // RLC coefficients (prio3.rs:2859-2862); only the first verifier_len + 5 are consumed (:2865-2871)
+        s.init_xof(P.alg_id, DST_RLC, vk0, vk1);
+        s.absorb(nonce, 16);
+        s.finalize();
+        xof_emit(s, reinterpret_cast<uint8_t *>(W.rlc + (uint64_t)i * (P.verifier_len + 5)), P.verifier_len + 5);
+
+        // testing id: AES128_vk(client_id.to_le_bytes()) (main.rs:51, common/src/prg.rs:650-655)
+        const uint8_t *sbox = aes_rk + 176;
+        uint8_t st[16], t[16];
+#pragma unroll
+        for (int b = 0; b < 16; b++) st[b] = d.base[15 - b] ^ aes_rk[b];
+#pragma unroll 1
+        for (int round = 1; round <= 10; round++) {
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) t[4 * c + r] = sbox[st[4 * ((c + r) & 3) + r]];
+            if (round < 10) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    uint8_t b0 = t[4 * c], b1 = t[4 * c + 1], b2 = t[4 * c + 2], b3 = t[4 * c + 3];
+#define XT(x) ((uint8_t)(((x) << 1) ^ ((((x) >> 7) & 1) * 0x1b)))
+                    t[4 * c] = XT(b0) ^ XT(b1) ^ b1 ^ b2 ^ b3;
+                    t[4 * c + 1] = b0 ^ XT(b1) ^ XT(b2) ^ b2 ^ b3;
+                    t[4 * c + 2] = b0 ^ b1 ^ XT(b2) ^ XT(b3) ^ b3;
+                    t[4 * c + 3] = XT(b0) ^ b0 ^ b1 ^ b2 ^ XT(b3);
+#undef XT
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 16; b++) st[b] = t[b] ^ aes_rk[16 * round + b];
+        }
+#pragma unroll
+        for (int b = 0; b < 16; b++) testing_ids[16ull * i + b] = st[b];
+    }
+}
+
+// --------------------------------------------------------------------------------- query ----
+// One wavefront per report.  Type::query for the ParallelSum<Mul> circuits (flp.rs:359-479,
+// types.rs:623-639, 410-437, 742-777) in barycentric form: wire w's polynomial evaluated at r
+// is sum_j L_j(r) f[w][j], with f[2k][j] = rho^(i+1) x_i, f[2k+1][j] = x_i - h, i = (j-1) chunk + k,
+// f[w][0] = proof[w]; v[0] = <s, G> (sum of the gadget polynomial over the call points).
+// Then decide on both public proofs (flp.rs:483-512), the differences, and the RLC tag
+// (prio3.rs:2703-2871).  `lds` holds L_j and M_j = L_j rho^(chunk (j-1)) per wave.
+__global__ void __launch_bounds__(256) k_query_psum(Prio3Dev P, Workspace W, uint32_t n, uint8_t *tags,
+                                                    uint8_t *out_shares, int32_t *status) {
+    extern __shared__ F128 lds[];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t i = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (i >= n) return;
+    uint8_t *tag_out = tags + 16ull * i;
+    F128 *out_row = reinterpret_cast<F128 *>(out_shares) + (uint64_t)i * P.output_len;
+    if (status[i] != ST_OK) {
+        for (uint32_t e = lane; e < P.output_len; e += 64) out_row[e] = f_zero();
+        if (lane == 0) st128(tag_out, f_zero());
+        return;
+    }
+    F128 *Lw = lds + (uint64_t)wave * 2 * P.n_weights, *Mw = Lw + P.n_weights;
+    const RepDesc d = W.desc[i];
+    const RepScal *sc = &W.scal[i];
+    const uint8_t *pp0 = d.tail + 40, *pp1 = pp0 + 16ull * P.verifier_len;
+    const F128 *rlc = W.rlc + (uint64_t)i * (P.verifier_len + 5);
+    const F128 r = sc->qr[1];
+    const F128 rho = sc->jr[P.jr_len];          // run 2's joint_rand[0]
+    const bool leader = d.role == 0;
+    uint32_t bad = 0;                           // any element >= p (FieldError::ModulusOverflow)
+
+    // weights to LDS; M_j = L_j * rho^(chunk (j-1))
+    const F128 *Lg = W.weights + (uint64_t)i * P.n_weights;
+    for (uint32_t j = lane; j < P.n_weights; j += 64) {
+        F128 l = Lg[j];
+        Lw[j] = l;
+        Mw[j] = j ? f_mul(l, f_pow_u32(rho, P.chunk * (j - 1))) : f_zero();
+    }
+    // each wave reads back only its own LDS rows: order the LDS writes before the reads of
+    // this wave (no workgroup barrier: other waves of the block may already have returned)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    F128 sumL = f_zero();                       // sum_{j>=1} L_j
+    for (uint32_t j = 1 + lane; j < P.n_weights; j += 64) sumL = f_add(sumL, Lw[j]);
+    sumL = wave_sum(sumL);
+    const F128 L0 = Lw[0];
+    const F128 h_sumL = f_mul(P.half, sumL);
+
+    // Leader only: proof share of run 1 is hashed, never evaluated; it still has to decode
+    if (leader)
+        for (uint32_t e = lane; e < P.proof_len; e += 64) {
+            F128 v = ld128(d.proof1 + 16ull * e);
+            bad |= !f_in_range(v.lo, v.hi);
+        }
+
+    F128 tag = f_zero();
+    F128 sum_x = f_zero();                      // Histogram's sum check
+    // wires
+    for (uint32_t k = lane; k < P.chunk; k += 64) {
+        F128 A = f_zero(), B = f_zero();
+        for (uint32_t j = 1; j < P.n_weights; j++) {
+            uint32_t idx = (j - 1) * P.chunk + k;
+            if (idx < P.input_len) {
+                F128 x = ld128(d.meas + 16ull * idx);
+                bad |= !f_in_range(x.lo, x.hi);
+                A = f_add(A, f_mul(Mw[j], x));
+                B = f_add(B, f_mul(Lw[j], x));
+                sum_x = f_add(sum_x, x);
+            }
+        }
+        F128 s_even = ld128(d.proof2 + 16ull * (2 * k)), s_odd = ld128(d.proof2 + 16ull * (2 * k + 1));
+        bad |= !f_in_range(s_even.lo, s_even.hi) | !f_in_range(s_odd.lo, s_odd.hi);
+        F128 v_even = f_add(f_mul(L0, s_even), f_mul(f_pow_u32(rho, k + 1), A));
+        F128 v_odd = f_sub(f_add(f_mul(L0, s_odd), B), h_sumL);
+        F128 q_even = ld128(pp1 + 16ull * (1 + 2 * k)), q_odd = ld128(pp1 + 16ull * (2 + 2 * k));
+        bad |= !f_in_range(q_even.lo, q_even.hi) | !f_in_range(q_odd.lo, q_odd.hi);
+        if (leader) { v_even = f_sub(v_even, q_even); v_odd = f_sub(v_odd, q_odd); }
+        tag = f_add(tag, f_add(f_mul(rlc[1 + 2 * k], v_even), f_mul(rlc[2 + 2 * k], v_odd)));
+    }
+    // gadget polynomial G = proof2[arity ..]: G(r) and <s, G>
+    const uint8_t *G = d.proof2 + 16ull * P.arity;
+    F128 g_at_r = f_zero(), v0 = f_zero();
+    {
+        F128 rpow = f_pow_u32(r, lane), r64 = f_sqr_n(r, 6);
+        for (uint32_t e = lane; e < P.gpoly_len; e += 64) {
+            F128 c = ld128(G + 16ull * e);
+            bad |= !f_in_range(c.lo, c.hi);
+            g_at_r = f_add(g_at_r, f_mul(c, rpow));
+            v0 = f_add(v0, f_mul(c, P.s_tab[e]));
+            rpow = f_mul(rpow, r64);
+        }
+    }
+    g_at_r = wave_sum(g_at_r);
+    v0 = wave_sum(v0);
+    if (P.circuit == CIRCUIT_HISTOGRAM) {
+        // types.rs:428-436: rho' * range_check + rho'^2 * (sum x - h)
+        F128 rho2 = sc->jr[P.jr_len + 1];
+        F128 sum_check = f_sub(wave_sum(sum_x), P.half);
+        v0 = f_add(f_mul(rho2, v0), f_mul(f_sqr(rho2), sum_check));
+    }
+
+    // decide on the two public proofs (prio3.rs:2762-2786): pp[0] == 0 and
+    // sum_k pp[1+2k] pp[2+2k] == pp[1+arity]
+    F128 dec[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const uint8_t *pp = t ? pp1 : pp0;
+        F128 acc = f_zero();
+        for (uint32_t k = lane; k < P.chunk; k += 64) {
+            F128 a = ld128(pp + 16ull * (1 + 2 * k)), b = ld128(pp + 16ull * (2 + 2 * k));
+            bad |= !f_in_range(a.lo, a.hi) | !f_in_range(b.lo, b.hi);
+            acc = f_add(acc, f_mul(a, b));
+        }
+        acc = wave_sum(acc);
+        F128 first = ld128(pp), last = ld128(pp + 16ull * (1 + P.arity));
+        bad |= !f_in_range(first.lo, first.hi) | !f_in_range(last.lo, last.hi);
+        bool ok = f_is_zero(first) && f_eq(acc, last);
+        dec[t] = ok ? f_zero() : f_one();
+    }
+
+    // truncate (types.rs:641-648 / 439-442) -> out share
+    if (P.circuit == CIRCUIT_SUMVEC) {
+        for (uint32_t e = lane; e < P.output_len; e += 64) {
+            const uint8_t *bits = d.meas + 16ull * e * P.bits;
+            F128 acc = f_zero();
+            for (uint32_t l = P.bits; l-- > 0;) acc = f_add(f_dbl(acc), ld128(bits + 16ull * l));
+            out_row[e] = acc;
+        }
+    } else {
+        for (uint32_t e = lane; e < P.output_len; e += 64) out_row[e] = ld128(d.meas + 16ull * e);
+    }
+
+    if (lane == 0) {
+        const uint32_t vl = P.verifier_len;
+        F128 q0 = ld128(pp1), qg = ld128(pp1 + 16ull * (1 + P.arity));
+        F128 d0 = leader ? f_sub(v0, q0) : v0;
+        F128 dg = leader ? f_sub(g_at_r, qg) : g_at_r;
+        tag = f_add(tag, f_mul(rlc[0], d0));
+        tag = f_add(tag, f_mul(rlc[1 + P.arity], dg));
+        tag = f_add(tag, f_mul(rlc[vl], dec[0]));
+        tag = f_add(tag, f_mul(rlc[vl + 1], dec[1]));
+        if (sc->rand_diff[0]) tag = f_add(tag, rlc[vl + 2]);
+        if (sc->rand_diff[1]) tag = f_add(tag, rlc[vl + 3]);
+        F128 hs = leader ? f_neg(sc->hash) : sc->hash;       // prio3.rs:2844-2855
+        tag = f_add(tag, f_mul(rlc[vl + 4], hs));
+    }
+    tag = wave_sum(tag);
+    bad = wave_or(bad);
+    if (bad) {
+        for (uint32_t e = lane; e < P.output_len; e += 64) out_row[e] = f_zero();
+        tag = f_zero();
+    }
+    if (lane == 0) {
+        if (bad) status[i] = ST_ERR_MODULUS;
+        // prepare_encoded_key: the Helper-role tag is negated (main.rs:53-59)
+        st128(tag_out, leader ? tag : f_neg(tag));
+    }
+}
+
+// ----------------------------------------------------------------------------- aggregate ----
+// Aggregatable::merge over the kept reports (vdaf.rs:658-676, main.rs:108-118): column sums
+// of out_shares[n][len] mod p.  Pure HBM streaming: 16 B per (report, element).  Each block
+// owns a slab of reports; sums are carried in 192 bits and reduced once.
+__global__ void __launch_bounds__(256) k_agg_partial(const F128 *rows, const uint8_t *keep, uint64_t n, uint32_t len,
+                                                     uint32_t rows_per_block, F128 *partials) {
+    uint64_t r0 = (uint64_t)blockIdx.x * rows_per_block;
+    uint64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+    const uint32_t tpr = len < blockDim.x ? len : blockDim.x;  // threads across one row
+    const uint32_t rstep = blockDim.x / tpr;                   // rows per sweep
+    const uint32_t sub = threadIdx.x / tpr, col0 = threadIdx.x % tpr;
+    if (sub >= rstep) return;
+    for (uint32_t e = col0; e < len; e += tpr) {
+        uint64_t lo = 0, hi = 0, ov = 0;
+        for (uint64_t r = r0 + sub; r < r1; r += rstep) {
+            if (keep && !keep[r]) continue;
+            F128 v = rows[r * len + e];
+            u128 s = (((u128)hi << 64) | lo) + f_u(v);
+            ov += s < f_u(v);
+            lo = (uint64_t)s; hi = (uint64_t)(s >> 64);
+        }
+        // fold the overflow count: ov * 2^128
+        F128 acc = f_reduce256(lo, hi, ov, 0);
+        partials[((uint64_t)blockIdx.x * rstep + sub) * len + e] = acc;
+    }
+}
+__global__ void k_agg_final(const F128 *partials, uint32_t nparts, uint32_t len, F128 *out) {
+    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= len) return;
+    F128 acc = f_zero();
+    for (uint32_t q = 0; q < nparts; q++) acc = f_add(acc, partials[(uint64_t)q * len + e]);
+    out[e] = acc;
+}
+
+// Heavy hitters (server-hh/src/main.rs:72-104, hhcore/src/bucket.rs:48-55): per-counter u32
+// wrapping sums over the kept clients' bucket vectors.  4 B per counter, HBM streaming.
+__global__ void __launch_bounds__(256) k_hh_sum_u32(const uint32_t *buckets, const uint8_t *keep, uint64_t n,
+                                                    uint64_t words, uint32_t clients_per_block, uint32_t *acc) {
+    uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (w >= words) return;
+    uint64_t c0 = (uint64_t)blockIdx.y * clients_per_block;
+    uint64_t c1 = c0 + clients_per_block < n ? c0 + clients_per_block : n;
+    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    if (w + 4 <= words && (words & 3) == 0) {
+        for (uint64_t c = c0; c < c1; c++) {
+            if (keep && !keep[c]) continue;
+            uint4 v = *reinterpret_cast<const uint4 *>(buckets + c * words + w);
+            a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
+        }
+        atomicAdd(acc + w, a0); atomicAdd(acc + w + 1, a1); atomicAdd(acc + w + 2, a2); atomicAdd(acc + w + 3, a3);
+    } else {
+        for (uint64_t q = w; q < words && q < w + 4; q++) {
+            uint32_t a = 0;
+            for (uint64_t c = c0; c < c1; c++)
+                if (!keep || keep[c]) a += buckets[c * words + q];
+            atomicAdd(acc + q, a);
+        }
+    }
+}
+
+// ------------------------------------------------------------------- unit-parity kernels ----
+__global__ void k_test_f128(const F128 *a, const F128 *b, F128 *out, uint32_t n, int op) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F128 r;
+    switch (op) {
+    case 0: r = f_add(a[i], b[i]); break;
+    case 1: r = f_sub(a[i], b[i]); break;
+    case 2: r = f_mul(a[i], b[i]); break;
+    default: r = f_inv(a[i]); break;
+    }
+    out[i] = r;
+}
+// XofShake128::seed_stream(seed, dst(alg_id, usage), binder).into_field_vec(n) per lane
+__global__ void k_test_xof(const uint8_t *seeds, uint32_t alg_id, uint32_t usage, const uint8_t *binder,
+                           uint32_t binder_len, uint32_t n_elems, uint8_t *out, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Sponge s;
+    s.init_xof(alg_id, usage, seeds + 16ull * i);
+    s.absorb(binder, binder_len);
+    s.finalize();
+    xof_emit(s, out + 16ull * n_elems * i, n_elems);
+}
+
+}  // namespace wh

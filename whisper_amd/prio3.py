@@ -1,0 +1,193 @@
+"""Host-side mirror of the reference's Prio3 server surface for the batched path.
+
+Names follow the Rust crate: `new_sum_vec_256` / `new_histogram_256` / `new_average_256`
+(batched-flpcp-rs/src/vdaf/prio3.rs:150-165, 300-313, 360-380), `BatchAggregator::prepare_batched`
+(vdaf.rs:508-520) -- here over a whole batch, as the GPU wants it -- `Aggregator::aggregate`
+(prio3.rs:2445-2456) and `Collector::unshard` (prio3.rs:2909-2921).  The per-report loop of
+server-batch-prio3 (main.rs:33-60, 75-91) is `Prio3.prepare_encoded_keys`.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import lib, Params, Sizes, WhError
+
+SUMVEC, HISTOGRAM, AVERAGE = 0, 1, 2
+P128 = 2**128 - 7 * 2**66 + 1
+AVG_BITS = 64  # bin-utils/src/lib.rs:34
+
+
+class Prio3Params:
+    def __init__(self, circuit, bits=0, length=0, chunk=0, num_aggregators=2):
+        self.c = Params(circuit, bits, length, chunk, num_aggregators, 0)
+        s = Sizes()
+        rc = lib.wh_prio3_sizes_of(C.byref(self.c), C.byref(s))
+        if rc:
+            raise WhError(rc, "invalid Prio3 parameters")
+        self.sizes = s
+
+    def __getattr__(self, name):
+        return getattr(self.sizes, name)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def shard_batched_many(params, measurements, nonces, rands, first_client_id=0, nthreads=8):
+    """CPU client: client-batch-prio3/src/main.rs:67-153 for n clients.
+
+    measurements: uint64 [n, words]; nonces: uint8 [n,16]; rands: uint8 [n,144].
+    Returns (leader_reports uint8 [n, leader_len], helper_reports uint8 [n, helper_len])."""
+    meas = np.ascontiguousarray(measurements, dtype=np.uint64)
+    if meas.ndim == 1:
+        meas = meas.reshape(-1, 1)
+    n = meas.shape[0]
+    nonces = np.ascontiguousarray(nonces, dtype=np.uint8).reshape(n, 16)
+    rands = np.ascontiguousarray(rands, dtype=np.uint8).reshape(n, 144)
+    s = params.sizes
+    lr = np.zeros((n, s.leader_report_len), np.uint8)
+    hr = np.zeros((n, s.helper_report_len), np.uint8)
+    rc = lib.wh_client_shard_many(C.byref(params.c), meas.ctypes.data, meas.shape[1], nonces.ctypes.data,
+                                  rands.ctypes.data, first_client_id, n, nthreads, lr.ctypes.data, hr.ctypes.data)
+    if rc:
+        raise WhError(rc, "shard_batched")
+    return lr, hr
+
+
+class Prio3:
+    """One Prio3 instance bound to one GPU (one wh_ctx)."""
+
+    def __init__(self, params, device=0):
+        self.params = params
+        self.sizes = params.sizes
+        self._ctx = C.c_void_p()
+        rc = lib.wh_ctx_create(device, C.byref(params.c), C.byref(self._ctx))
+        if rc:
+            raise WhError(rc, "wh_ctx_create (is a GPU present? there is no CPU fallback)")
+        self.n_last = 0
+
+    def close(self):
+        if self._ctx:
+            lib.wh_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc:
+            raise WhError(rc, f"{what}: {lib.wh_last_error(self._ctx).decode()}")
+
+    @property
+    def stream(self):
+        return lib.wh_ctx_stream(self._ctx)
+
+    def synchronize(self):
+        self._chk(lib.wh_ctx_synchronize(self._ctx), "synchronize")
+
+    def output_len(self):
+        return self.sizes.output_len
+
+    def verifier_len(self):
+        return self.sizes.verifier_len
+
+    # ---- host-buffer path (what the Rust servers hold: Vec<Vec<u8>>) ----
+    def prepare_encoded_keys(self, verify_key, reports):
+        """run_vdaf_prepare's map over prepare_encoded_key (server-batch-prio3/src/main.rs:75-91).
+
+        reports: list of bytes.  Returns (tags [n,16] u8, testing_ids [n,16] u8, status [n] i32)."""
+        n = len(reports)
+        offsets = np.zeros(n + 1, np.uint64)
+        if n:
+            offsets[1:] = np.cumsum([len(r) for r in reports])
+        blob = np.frombuffer(b"".join(reports) + b"\0", dtype=np.uint8)
+        return self.prepare_batch_host(verify_key, blob, offsets)
+
+    def prepare_batch_host(self, verify_key, blob, offsets):
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        n = len(offsets) - 1
+        tags = np.zeros((n, 16), np.uint8)
+        ids = np.zeros((n, 16), np.uint8)
+        status = np.zeros(n, np.int32)
+        vk = np.frombuffer(bytes(verify_key), dtype=np.uint8)
+        self._chk(lib.wh_prio3_prepare_batch(self._ctx, vk.ctypes.data, blob.ctypes.data, offsets.ctypes.data, n,
+                                             tags.ctypes.data, ids.ctypes.data, status.ctypes.data), "prepare_batch")
+        self.n_last = n
+        return tags, ids, status
+
+    def out_shares(self):
+        out = np.zeros((self.n_last, 16 * self.sizes.output_len), np.uint8)
+        self._chk(lib.wh_prio3_out_shares(self._ctx, out.ctypes.data), "out_shares")
+        return out
+
+    def aggregate(self, keep=None):
+        """Aggregator::aggregate over the kept reports of the last batch -> bytes(output_len*16)."""
+        if keep is not None:
+            keep = np.ascontiguousarray(keep, dtype=np.uint8)
+            assert len(keep) == self.n_last
+        agg = np.zeros(16 * self.sizes.output_len, np.uint8)
+        self._chk(lib.wh_prio3_aggregate(self._ctx, _ptr(keep), agg.ctypes.data), "aggregate")
+        return agg
+
+    # ---- device-pointer path (inputs resident in HBM; torch tensors supply the memory) ----
+    def prepare_batch_dev(self, verify_key, d_blob, d_offsets, n, d_tags, d_ids, d_status):
+        vk = np.frombuffer(bytes(verify_key), dtype=np.uint8)
+        self._chk(lib.wh_prio3_prepare_batch_dev(self._ctx, vk.ctypes.data, d_blob, d_offsets, n, d_tags, d_ids,
+                                                 d_status), "prepare_batch_dev")
+        self.n_last = n
+
+    def aggregate_dev(self, d_keep, d_agg):
+        self._chk(lib.wh_prio3_aggregate_dev(self._ctx, d_keep, d_agg), "aggregate_dev")
+
+    def sum_rows_dev(self, d_rows, n_rows, length, d_keep, d_out):
+        self._chk(lib.wh_f128_sum_rows_dev(self._ctx, d_rows, n_rows, length, d_keep, d_out), "sum_rows_dev")
+
+    def hh_bucket_sum_u32_dev(self, d_buckets, d_keep, n, words, d_acc):
+        self._chk(lib.wh_hh_bucket_sum_u32_dev(self._ctx, d_buckets, d_keep, n, words, d_acc), "hh_bucket_sum")
+
+    # ---- unit-parity surface ----
+    def test_f128_op(self, op, a, b=None):
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        n = a.size // 16
+        out = np.zeros(a.size, np.uint8)
+        bp = None
+        if b is not None:
+            b = np.ascontiguousarray(b, dtype=np.uint8)
+            bp = b.ctypes.data
+        self._chk(lib.wh_test_f128_op(self._ctx, op, a.ctypes.data, bp, out.ctypes.data, n), "test_f128_op")
+        return out
+
+    def test_xof_expand(self, seeds, alg_id, usage, binder, n_elems):
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint8)
+        n = seeds.size // 16
+        out = np.zeros((n, 16 * n_elems), np.uint8)
+        b = np.frombuffer(bytes(binder) + b"\0", dtype=np.uint8)
+        self._chk(lib.wh_test_xof_expand(self._ctx, seeds.ctypes.data, n, alg_id, usage, b.ctypes.data, len(binder),
+                                         n_elems, out.ctypes.data), "test_xof_expand")
+        return out
+
+    @staticmethod
+    def unshard(agg_shares):
+        """Collector::unshard (prio3.rs:2909-2921): element-wise sum of the aggregate shares."""
+        n = len(agg_shares[0]) // 16
+        out = []
+        for e in range(n):
+            out.append(sum(int.from_bytes(bytes(a[16 * e:16 * e + 16]), "little") for a in agg_shares) % P128)
+        return out
+
+
+def new_sum_vec_256(num_aggregators, bits, length, chunk_length, device=0):
+    return Prio3(Prio3Params(SUMVEC, bits, length, chunk_length, num_aggregators), device)
+
+
+def new_histogram_256(num_aggregators, length, chunk_length, device=0):
+    return Prio3(Prio3Params(HISTOGRAM, 0, length, chunk_length, num_aggregators), device)
+
+
+def new_average_256(num_aggregators, bits=AVG_BITS, device=0):
+    return Prio3(Prio3Params(AVERAGE, bits, 0, 0, num_aggregators), device)
