@@ -2,6 +2,11 @@
 import ctypes as C
 import os
 
+# torch supplies device memory, streams and torch.distributed (RCCL) around this library.  It ships
+# its own libamdhip64 under the same SONAME; loading torch first makes this library bind to that one
+# copy instead of bringing a second HIP runtime into the process (the second one sees no GPU).
+import torch  # noqa: F401
+
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwhisper_gfx950.so")
 if not os.path.exists(LIB_PATH):
     raise ImportError(
