@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: batched Prio3 verification + aggregation on MI355X.
+
+One step = one pass over one batch of encoded client reports already resident in HBM:
+  wh_prio3_prepare_batch_dev (parse, Helper expansion, Fiat-Shamir hashing, query + RLC tag)
+  + wh_prio3_aggregate_dev (masked sum of out shares)
+  + for N > 1: RCCL all-gather of the per-GPU partial aggregates and an on-GPU mod-p reduction.
+Reports shard across ranks with no data-path collective (weak scaling: fixed reports per GPU).
+
+  python bench.py --gpus 1 --steps 5 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import whisper_amd as W  # noqa: E402
+
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from common import VK, make_reports  # noqa: E402  (deterministic synthetic clients; no oracle involved)
+
+WORKLOADS = {
+    # BASELINE.json configs[2]: Prio3 SumVec large vec_size/chunk_size, 1M clients over 8 GPUs
+    "sumvec_large": dict(circuit=W.SUMVEC, bits=16, length=1024, chunk=128, reports_per_gpu=125_000,
+                         desc="Prio3 SumVec bits=16 vec_size=1024 chunk_size=128, 125k reports/GPU (1M clients over 8 GPUs)"),
+    # BASELINE.json configs[0]: the reference's own configs/prio3-server-{alice,bob}.json sizes
+    "sumvec_cfg1": dict(circuit=W.SUMVEC, bits=16, length=128, chunk=64, reports_per_gpu=500_000,
+                        desc="Prio3 SumVec bits=16 vec_size=128 chunk_size=64 (configs/prio3-server-alice.json sizes)"),
+    # BASELINE.json configs[1]
+    "histogram": dict(circuit=W.HISTOGRAM, bits=0, length=128, chunk=64, reports_per_gpu=100_000,
+                      desc="Prio3 Histogram length=128 chunk_size=64, 100k clients"),
+}
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def alg_bytes_per_report(s, role):
+    """Algorithmic bytes each kernel must move for one report ('Kernels')."""
+    IL, PL, VL, OL, C = s.input_len, s.proof_len, s.verifier_len, s.output_len, s.calls
+    hash_rd = 16 * IL + 32 * PL + 32 * VL + 64 + 64 + 16 + 16 + 16 + 16     # absorbed bytes: meas, 2 proofs, pp, parts, blinds, nonce, id
+    hash_wr = 16 * (VL + 5) + 16 * (C + 1) + 112 + 16                        # rlc, weights, scalars, testing id
+    query_rd = 16 * IL + 16 * PL + 32 * VL + 16 * (VL + 5) + 16 * (C + 1) + 112 + (16 * PL if role == 0 else 0)
+    query_wr = 16 * OL + 16
+    expand = (64 + 16 * (IL + 2 * PL)) if role == 1 else 0
+    return {"expand": expand, "hash": hash_rd + hash_wr, "query": query_rd + query_wr, "parse": 64 + 56, "aggregate": 16 * OL + 1}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="sumvec_large", choices=sorted(WORKLOADS))
+    ap.add_argument("--reports-per-gpu", type=int, default=0)
+    ap.add_argument("--unique", type=int, default=128, help="distinct clients generated on the CPU and tiled")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the measured path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    wl = WORKLOADS[args.workload]
+    n = args.reports_per_gpu or wl["reports_per_gpu"]
+    params = W.Prio3Params(wl["circuit"], wl["bits"], wl["length"], wl["chunk"])
+    s = params.sizes
+    K = max(1, min(args.unique, n // 2 if n >= 2 else 1))
+    nthreads = max(1, min(16, os.cpu_count() or 1))
+
+    # ---- synthetic clients: K distinct clients sharded on the CPU; this server sees the Leader
+    # share of even clients and the Helper share of odd ones (client-batch-prio3 main.rs:114-115)
+    t_gen = time.time()
+    lr, hr, _ = make_reports(params, 2 * K, seed=1000 + rank, first_client_id=rank << 40, nthreads=nthreads)
+    tile_reports = [(lr[i] if i % 2 == 0 else hr[i]) for i in range(2 * K)]
+    tile = np.concatenate(tile_reports)
+    tile_off = np.zeros(2 * K + 1, np.int64)
+    tile_off[1:] = np.cumsum([len(r) for r in tile_reports])
+    t_gen = time.time() - t_gen
+    reps = (n + 2 * K - 1) // (2 * K)
+    d_tile = torch.from_numpy(tile).to(dev)
+    d_blob = d_tile.repeat(reps)
+    offs = (torch.from_numpy(tile_off[:-1]).to(dev)[None, :] + (torch.arange(reps, device=dev, dtype=torch.int64) * int(tile_off[-1]))[:, None]).reshape(-1)
+    d_off = torch.cat([offs, torch.tensor([reps * int(tile_off[-1])], device=dev, dtype=torch.int64)])[: n + 1].contiguous()
+    d_tags = torch.zeros(16 * n, dtype=torch.uint8, device=dev)
+    d_ids = torch.zeros(16 * n, dtype=torch.uint8, device=dev)
+    d_status = torch.zeros(n, dtype=torch.int32, device=dev)
+    keep = np.ones(n, np.uint8)
+    keep[:: 1000] = 0                      # ~0.1 % of the clients flagged by the group test
+    d_keep = torch.from_numpy(keep).to(dev)
+    d_agg = torch.zeros(16 * s.output_len, dtype=torch.uint8, device=dev)
+    d_gather = torch.zeros(world * 16 * s.output_len, dtype=torch.uint8, device=dev)
+    d_total = torch.zeros(16 * s.output_len, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    vdaf = W.Prio3(params, device=local_rank)
+    ext = torch.cuda.ExternalStream(vdaf.stream, device=dev)
+
+    def step():
+        vdaf.prepare_batch_dev(VK, d_blob.data_ptr(), d_off.data_ptr(), n, d_tags.data_ptr(), d_ids.data_ptr(), d_status.data_ptr())
+        vdaf.aggregate_dev(d_keep.data_ptr(), d_agg.data_ptr())
+        if world > 1:
+            with torch.cuda.stream(ext):
+                dist.all_gather_into_tensor(d_gather, d_agg)
+            vdaf.sum_rows_dev(d_gather.data_ptr(), world, s.output_len, None, d_total.data_ptr())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        vdaf.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    vdaf.set_profiling(True)
+    vdaf.kernel_times(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ktimes = vdaf.kernel_times(reset=True)
+    vdaf.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    n_bad_status = int((d_status != 0).sum().item())
+
+    # ---- per-kernel roofline numbers (rank 0), HIP events on the launch stream
+    n_lead = (n + 1) // 2
+    n_help = n // 2
+    per = {k: n_lead * alg_bytes_per_report(s, 0)[k] + n_help * alg_bytes_per_report(s, 1)[k]
+           for k in ("parse", "expand", "hash", "query", "aggregate")}
+    kernels = {}
+    for k, (ms, cnt) in ktimes.items():
+        if cnt:
+            kernels[k] = {"ms_per_step": ms / args.steps, "launches_per_step": cnt / args.steps}
+    dom = max((k for k in kernels if k in per), key=lambda k: kernels[k]["ms_per_step"])
+    launches = kernels[dom]["launches_per_step"]
+    avg_ms = kernels[dom]["ms_per_step"] / launches
+    bytes_per_launch = per[dom] / launches
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+    # SHAKE128 work of the step, for the VALU side of the story
+    def perms(role):
+        IL, PL, VL = s.input_len, s.proof_len, s.verifier_len
+        blk = lambda nbytes: -(-nbytes // 168)
+        jr = blk(42 + 16 * IL + 1)
+        qr = blk(25 + 32 * s.joint_rand_len + 32 * PL + 1)
+        hs = blk(25 + 64 + 32 * VL + 1)
+        rlc = 1 + blk(16 * (VL + 5)) - 1 + 1
+        small = 2 + 2 + 1 + 2 + 1 + 1
+        ex = (blk(16 * IL) + 2 * blk(16 * PL) + 3) if role == 1 else 0
+        return jr + qr + hs + rlc + small + ex
+    total_perms = n_lead * perms(0) + n_help * perms(1)
+
+    result = None
+    if rank == 0:
+        value = world * n * args.steps / elapsed
+        result = {
+            "metric": "verified+aggregated client reports/sec (node), Prio3 SumVec" if wl["circuit"] == W.SUMVEC else
+                      "verified+aggregated client reports/sec (node), Prio3 Histogram",
+            "value": value, "unit": "reports/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u128 (Field128 mod p) + u64 (Keccak lanes)", "data": "synthetic",
+            "config": {"workload": wl["desc"], "reports_per_gpu": n, "distinct_clients_tiled": 2 * K,
+                       "leader_report_bytes": s.leader_report_len, "helper_report_bytes": s.helper_report_len,
+                       "roles": "alternating Leader/Helper", "inputs": "resident in HBM",
+                       "parallelism": f"reports sharded over {world} GPU(s); all-gather + mod-p reduce of partial aggregates",
+                       "status_nonzero": n_bad_status, "client_gen_s": round(t_gen, 2)},
+            "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": avg_ms, "alg_bytes_per_launch": bytes_per_launch,
+                         "note": "the verify kernels are integer-VALU bound (SHAKE128 + Field128), not HBM bound; see valu"},
+            "valu": {"keccak_f1600_per_step": total_perms,
+                     "keccak_f1600_per_s": total_perms * args.steps / elapsed,
+                     "note": "one Keccak-f[1600] is ~6.2k 32-bit VALU lane-ops; chip peak 256 CU x 128 lanes x 2.4 GHz = 78.6 T lane-ops/s"},
+            "kernels": kernels,
+        }
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(wl, tile_reports, nthreads, args.cpu_seconds)
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    vdaf.close()
+    return result
+
+
+def cpu_baseline(wl, reports, nthreads, budget_s):
+    """The oracle (CPU restatement of the reference's algorithm as written: per-wire inverse FFT +
+    Horner, both runs, SHAKE128 per report) timed on this host's cores over a bounded sample of the
+    same reports.  The only place bench.py touches oracle/."""
+    import oracle_lib as O
+    op = O.params(wl["circuit"], wl["bits"], wl["length"], wl["chunk"])
+    sample = list(reports[: max(2, 2 * nthreads)])
+    done, spent = 0, 0.0
+    while True:
+        offsets = np.zeros(len(sample) + 1, np.uint64)
+        offsets[1:] = np.cumsum([len(r) for r in sample])
+        blob = np.concatenate(sample)
+        t0 = time.perf_counter()
+        _, _, status, outs = O.prio3_prepare_batch(op, VK, blob, offsets, nthreads=nthreads)
+        O.prio3_aggregate(outs, O.sizes(op).output_len)
+        dt = time.perf_counter() - t0
+        assert not status.any()
+        done, spent = len(sample), dt
+        if dt >= budget_s / 2:
+            break
+        # grow the sample (cycling through the distinct reports) towards the time budget
+        want = int(len(sample) * min(8.0, budget_s / max(dt, 1e-3)))
+        want -= want % 2
+        if want <= len(sample):
+            break
+        sample = [reports[i % len(reports)] for i in range(want)]
+    return {"value": done / spent, "unit": "reports/s", "cores": nthreads, "kind": "port",
+            "sample": f"{done} reports (alternating Leader/Helper) of the same workload in {spent:.2f} s, "
+                      f"{nthreads} threads; oracle/ = C restatement of the reference algorithm as written"}
+
+
+if __name__ == "__main__":
+    main()

@@ -33,6 +33,13 @@ struct wh_ctx {
     uint8_t *d_blob = nullptr; uint64_t blob_cap = 0;
     uint64_t *d_offsets = nullptr; uint64_t off_cap = 0;
     uint8_t *d_tags = nullptr, *d_ids = nullptr; uint64_t tags_cap = 0, ids_cap = 0;
+    // optional per-kernel timing with HIP events on the context stream (wh_ctx_set_profiling)
+    bool profiling = false;
+    struct Ev { hipEvent_t a, b; int id; };
+    std::vector<Ev> evs;
+    std::vector<hipEvent_t> ev_pool;
+    double k_ms[WH_NUM_KERNELS] = {0};
+    uint64_t k_launches[WH_NUM_KERNELS] = {0};
     std::string err;
 };
 
@@ -46,6 +53,23 @@ namespace {
             return WH_ERR_HIP;                                                                    \
         }                                                                                         \
     } while (0)
+
+hipEvent_t ev_get(wh_ctx *c) {
+    if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+// brackets one kernel launch with events when profiling is on
+struct KTimer {
+    wh_ctx *c; hipEvent_t a = nullptr, b = nullptr; int id;
+    KTimer(wh_ctx *c_, int id_) : c(c_), id(id_) {
+        if (c->profiling) { a = ev_get(c); b = ev_get(c); if (a) (void)hipEventRecord(a, c->stream); }
+    }
+    ~KTimer() {
+        if (c->profiling && a && b) { (void)hipEventRecord(b, c->stream); c->evs.push_back({a, b, id}); }
+    }
+};
 
 template <typename T>
 int32_t ensure(wh_ctx *c, T *&ptr, uint64_t &cap, uint64_t want) {
@@ -108,9 +132,11 @@ uint64_t pick_cap(const wh_ctx *c, uint64_t n) {
     uint64_t by_mem = (24ull << 30) / (hrow + 4096);   // <= 24 GiB of expansion rows
     uint64_t cap = 1ull << 19;
     if (cap > by_mem) cap = by_mem;
-    if (cap > n) cap = n;
     if (cap < 64) cap = 64;
-    return cap;
+    if (n <= cap) return n < 64 ? 64 : n;
+    // equal-sized sub-batches, so that the last one does not leave the chip half empty
+    const uint64_t parts = (n + cap - 1) / cap;
+    return (n + parts - 1) / parts;
 }
 
 }  // namespace
@@ -180,6 +206,8 @@ void wh_ctx_destroy(wh_ctx *c) {
                     c->d_blob, c->d_offsets, c->d_tags, c->d_ids, c->W.desc, c->W.scal, c->W.weights, c->W.rlc,
                     c->W.hrows, c->W.hlist, c->W.counters};
     for (void *p : ptrs) if (p) hipFree(p);
+    for (auto &e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    for (auto e : c->ev_pool) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -221,14 +249,18 @@ int32_t wh_prio3_prepare_batch_dev(wh_ctx *c, const uint8_t verify_key[16], cons
         const uint32_t nb = (uint32_t)((n - base < c->cap) ? n - base : c->cap);
         const uint32_t npad = (nb + 255) / 256 * 256;
         HIPCHK(c, hipMemsetAsync(c->W.counters, 0, 64, c->stream));
+        { KTimer t_(c, WH_K_PARSE);
         hipLaunchKernelGGL(k_parse, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, d_blob, d_offsets + base, nb,
-                           d_status + base);
-        hipLaunchKernelGGL(k_expand, dim3(2 * npad / 256), dim3(256), 0, c->stream, c->P, c->W, npad);
+                           d_status + base); }
+        { KTimer t_(c, WH_K_EXPAND);
+        hipLaunchKernelGGL(k_expand, dim3(2 * npad / 256), dim3(256), 0, c->stream, c->P, c->W, npad); }
+        { KTimer t_(c, WH_K_HASH);
         hipLaunchKernelGGL(k_hash, dim3(2 * npad / 256), dim3(256), 0, c->stream, c->P, c->W, nb, npad, vk0, vk1,
-                           c->d_aes, d_ids + 16 * base, d_status + base);
+                           c->d_aes, d_ids + 16 * base, d_status + base); }
+        { KTimer t_(c, WH_K_QUERY);
         hipLaunchKernelGGL(k_query_psum, dim3((nb + 3) / 4), dim3(256), lds, c->stream, c->P, c->W, nb,
                            d_tags + 16 * base, reinterpret_cast<uint8_t *>(c->d_out_shares + base * z.output_len),
-                           d_status + base);
+                           d_status + base); }
         HIPCHK(c, hipGetLastError());
     }
     return WH_OK;
@@ -285,8 +317,9 @@ static int32_t sum_rows(wh_ctx *c, const F128 *rows, const uint8_t *d_keep, uint
     const uint32_t nblocks = (uint32_t)((n + rpb - 1) / rpb);
     if (n == 0) { HIPCHK(c, hipMemsetAsync(d_out, 0, len * sizeof(F128), c->stream)); return WH_OK; }
     if ((rc = ensure(c, c->d_partials, c->partials_cap, (uint64_t)nblocks * rstep * len))) return rc;
+    { KTimer t_(c, WH_K_AGG);
     hipLaunchKernelGGL(k_agg_partial, dim3(nblocks), dim3(256), 0, c->stream, rows, d_keep, n, len, (uint32_t)rpb, c->d_partials);
-    hipLaunchKernelGGL(k_agg_final, dim3((len + 255) / 256), dim3(256), 0, c->stream, c->d_partials, nblocks * rstep, len, d_out);
+    hipLaunchKernelGGL(k_agg_final, dim3((len + 255) / 256), dim3(256), 0, c->stream, c->d_partials, nblocks * rstep, len, d_out); }
     HIPCHK(c, hipGetLastError());
     return WH_OK;
 }
@@ -344,8 +377,32 @@ int32_t wh_hh_bucket_sum_u32_dev(wh_ctx *c, const uint32_t *d_buckets, const uin
     uint32_t gy = 4096 / gx; if (gy < 1) gy = 1; if (gy > n) gy = (uint32_t)n; if (gy > 65535) gy = 65535;
     const uint32_t cpb = (uint32_t)((n + gy - 1) / gy);
     gy = (uint32_t)((n + cpb - 1) / cpb);
-    hipLaunchKernelGGL(k_hh_sum_u32, dim3(gx, gy), dim3(256), 0, c->stream, d_buckets, d_keep, n, words, cpb, d_acc);
+    { KTimer t_(c, WH_K_HH);
+    hipLaunchKernelGGL(k_hh_sum_u32, dim3(gx, gy), dim3(256), 0, c->stream, d_buckets, d_keep, n, words, cpb, d_acc); }
     HIPCHK(c, hipGetLastError());
+    return WH_OK;
+}
+
+int32_t wh_ctx_set_profiling(wh_ctx *c, int32_t on) {
+    if (!c) return WH_ERR_PARAM;
+    c->profiling = on != 0;
+    return WH_OK;
+}
+
+int32_t wh_ctx_kernel_times(wh_ctx *c, double *ms, uint64_t *launches, int32_t reset) {
+    if (!c || !ms || !launches) return WH_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto &e : c->evs) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, e.a, e.b) == hipSuccess) { c->k_ms[e.id] += t; c->k_launches[e.id]++; }
+        c->ev_pool.push_back(e.a); c->ev_pool.push_back(e.b);
+    }
+    c->evs.clear();
+    for (int i = 0; i < WH_NUM_KERNELS; i++) {
+        ms[i] = c->k_ms[i]; launches[i] = c->k_launches[i];
+        if (reset) { c->k_ms[i] = 0; c->k_launches[i] = 0; }
+    }
     return WH_OK;
 }
 

@@ -150,6 +150,19 @@ class Prio3:
     def hh_bucket_sum_u32_dev(self, d_buckets, d_keep, n, words, d_acc):
         self._chk(lib.wh_hh_bucket_sum_u32_dev(self._ctx, d_buckets, d_keep, n, words, d_acc), "hh_bucket_sum")
 
+    # ---- measurement ----
+    KERNELS = ("parse", "expand", "hash", "query", "aggregate", "hh_sum")
+
+    def set_profiling(self, on=True):
+        self._chk(lib.wh_ctx_set_profiling(self._ctx, int(on)), "set_profiling")
+
+    def kernel_times(self, reset=True):
+        """{kernel: (total_ms, launches)} measured with HIP events on the context stream."""
+        ms = np.zeros(len(self.KERNELS), np.float64)
+        cnt = np.zeros(len(self.KERNELS), np.uint64)
+        self._chk(lib.wh_ctx_kernel_times(self._ctx, ms.ctypes.data, cnt.ctypes.data, int(reset)), "kernel_times")
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.KERNELS)}
+
     # ---- unit-parity surface ----
     def test_f128_op(self, op, a, b=None):
         a = np.ascontiguousarray(a, dtype=np.uint8)
