@@ -10,6 +10,8 @@
 
 using namespace wh;
 
+namespace wh { void launch_expand(const Prio3Dev &P, const Workspace &W, uint32_t npad, hipStream_t stream); }
+
 struct wh_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -129,7 +131,7 @@ int32_t alloc_workspace(wh_ctx *c, uint64_t cap) {
 // sub-batch size: enough lanes to fill the chip several times over, bounded by HBM scratch
 uint64_t pick_cap(const wh_ctx *c, uint64_t n) {
     const uint64_t hrow = 16ull * (c->z.input_len + 2ull * c->z.proof_len);
-    uint64_t by_mem = (24ull << 30) / (hrow + 4096);   // <= 24 GiB of expansion rows
+    uint64_t by_mem = (64ull << 30) / (hrow + 4096);   // <= 64 GiB of expansion rows (288 GB HBM)
     uint64_t cap = 1ull << 19;
     if (cap > by_mem) cap = by_mem;
     if (cap < 64) cap = 64;
@@ -253,7 +255,7 @@ int32_t wh_prio3_prepare_batch_dev(wh_ctx *c, const uint8_t verify_key[16], cons
         hipLaunchKernelGGL(k_parse, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, d_blob, d_offsets + base, nb,
                            d_status + base); }
         { KTimer t_(c, WH_K_EXPAND);
-        hipLaunchKernelGGL(k_expand, dim3(2 * npad / 256), dim3(256), 0, c->stream, c->P, c->W, npad); }
+        launch_expand(c->P, c->W, npad, c->stream); }
         { KTimer t_(c, WH_K_HASH);
         hipLaunchKernelGGL(k_hash, dim3(2 * npad / 256), dim3(256), 0, c->stream, c->P, c->W, nb, npad, vk0, vk1,
                            c->d_aes, d_ids + 16 * base, d_status + base); }

@@ -1,0 +1,39 @@
+// Helper share expansion kernel, in its own translation unit (see the note in kernels.hip).
+#include <hip/hip_runtime.h>
+#include "keccak.hpp"
+#include "prio3_dev.hpp"
+
+namespace wh {
+
+// -------------------------------------------------------------------------------- expand ----
+// Helper share expansion (prio3.rs:2480-2536): P::seed_stream(seed, dst(usage), [agg_id])
+// .into_field_vec(n).  Jobs [0, npad) expand the measurement share, jobs [npad, 2 npad) the two
+// proof shares, so a wave never mixes the two shapes.  Every sponge of a lane runs through the
+// same loop body (one copy of the permutation code, small register footprint).
+__global__ void __launch_bounds__(256) k_expand(Prio3Dev P, Workspace W, uint32_t npad) {
+    uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t nh = W.counters[0];
+    uint32_t which = job >= npad;
+    uint32_t slot = which ? job - npad : job;
+    if (slot >= nh) return;
+    const RepDesc d = W.desc[W.hlist[slot]];
+    const uint8_t *seeds = d.base + 49;  // meas_seed | proof1_seed | jr_blind | proof2_seed
+    Sponge s;
+    const uint32_t nst = which ? 2 : 1;
+#pragma unroll 1
+    for (uint32_t t = 0; t < nst; t++) {
+        const uint8_t *seed = which ? seeds + (t ? 48 : 16) : seeds;
+        uint8_t *out = const_cast<uint8_t *>(which ? (t ? d.proof2 : d.proof1) : d.meas);
+        s.init_xof(P.alg_id, which ? DST_PROOF : DST_MEAS, seed);
+        s.absorb3(d.base + 48, 1, nullptr, 0, nullptr, 0);   // binder = [agg_id]
+        s.finalize();
+        xof_emit(s, out, which ? P.proof_len : P.input_len);
+    }
+}
+
+
+void launch_expand(const Prio3Dev &P, const Workspace &W, uint32_t npad, hipStream_t stream) {
+    hipLaunchKernelGGL(k_expand, dim3(2 * npad / 256), dim3(256), 0, stream, P, W, npad);
+}
+
+}  // namespace wh

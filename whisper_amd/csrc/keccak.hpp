@@ -37,7 +37,24 @@ static const uint64_t KECCAK_RC_HOST[24] = {
     0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
     0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
 
-WH_HD uint64_t rotl64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
+// 64-bit rotate by a compile-time amount.  On the device it is two v_alignbit_b32 (a 64-bit
+// funnel over the register pair); left to itself hipcc emits 64-bit shifts + ORs.
+WH_HD uint64_t rotl64(uint64_t x, int n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32), nlo, nhi;
+    if (n == 32) { nlo = hi; nhi = lo; }
+    else if (n < 32) {
+        nlo = __builtin_amdgcn_alignbit(lo, hi, 32 - n);
+        nhi = __builtin_amdgcn_alignbit(hi, lo, 32 - n);
+    } else {
+        nlo = __builtin_amdgcn_alignbit(hi, lo, 64 - n);
+        nhi = __builtin_amdgcn_alignbit(lo, hi, 64 - n);
+    }
+    return ((uint64_t)nhi << 32) | nlo;
+#else
+    return (x << n) | (x >> (64 - n));
+#endif
+}
 
 // One Keccak-f[1600] round, all indices static.
 #define WH_KECCAK_ROUND(a, rc)                                                                   \
@@ -160,29 +177,36 @@ struct Sponge {
     }
     WH_HD void absorb_f(const F128 &v) { absorb_u64(v.lo); absorb_u64(v.hi); }
 
-    // absorb `len` bytes at `p` (any alignment).  Whole rate blocks take the static-index
-    // path; the stretch before the first block boundary and the tail take the word/byte path.
-    WH_HD void absorb(const uint8_t *p, uint32_t len) {
+    // Absorb up to three byte segments (any alignment, any lengths) back to back.  The state
+    // is permuted in exactly one place: steps only XOR and advance `pos`, and a full block
+    // (pos == RATE) is permuted at the top of the loop.  Whole rate blocks take the static-index
+    // path; the stretch before the first block boundary, seams and tails go word / byte wise.
+    WH_HD void absorb3(const uint8_t *p, uint32_t len, const uint8_t *p2, uint32_t len2, const uint8_t *p3,
+                       uint32_t len3) {
         for (;;) {
-            if (pos == 0) {
-                while (len >= SHAKE128_RATE) {
-#pragma unroll
-                    for (int i = 0; i < (int)RATE_WORDS; i++) st[i] ^= ld64(p + 8 * i);
-                    keccak_f1600(st);
-                    p += SHAKE128_RATE;
-                    len -= SHAKE128_RATE;
-                }
+            if (pos == SHAKE128_RATE) { keccak_f1600(st); pos = 0; }
+            if (!len) {
+                if (!len2 && !len3) break;
+                p = p2; len = len2; p2 = p3; len2 = len3; len3 = 0;
+                continue;
             }
-            if (!len) break;
-            if (len >= 8 && pos + 8 <= SHAKE128_RATE) {
-                absorb_u64(ld64(p));
-                p += 8; len -= 8;
+            if (pos == 0 && len >= SHAKE128_RATE) {
+#pragma unroll
+                for (int i = 0; i < (int)RATE_WORDS; i++) st[i] ^= ld64(p + 8 * i);
+                p += SHAKE128_RATE; len -= SHAKE128_RATE; pos = SHAKE128_RATE;
+            } else if (len >= 8 && pos + 8 <= SHAKE128_RATE) {
+                uint64_t w = ld64(p);
+                uint32_t sh = (pos & 7) * 8, idx = pos >> 3;
+                xor_word(idx, w << sh);
+                if (sh) xor_word(idx + 1, w >> (64 - sh));
+                p += 8; len -= 8; pos += 8;
             } else {
-                absorb_byte(*p++);
-                len--;
+                xor_word(pos >> 3, (uint64_t)(*p) << (8 * (pos & 7)));
+                p++; len--; pos++;
             }
         }
     }
+    WH_HD void absorb(const uint8_t *p, uint32_t len) { absorb3(p, len, nullptr, 0, nullptr, 0); }
 
     // SHAKE128 padding (0x1f ... 0x80) and the permutation that yields the first output block
     WH_HD void finalize() {

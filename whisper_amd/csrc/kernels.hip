@@ -105,49 +105,17 @@ __global__ void k_parse(Prio3Dev P, Workspace W, const uint8_t *blob, const uint
     status[i] = st;
 }
 
-// -------------------------------------------------------------------------------- expand ----
-// Helper share expansion (prio3.rs:2480-2536): P::seed_stream(seed, dst(usage), [agg_id])
-// .into_field_vec(n).  Jobs [0, npad) expand the measurement share, jobs [npad, 2 npad) the two
-// proof shares, so a wave never mixes the two shapes.
-__global__ void __launch_bounds__(256) k_expand(Prio3Dev P, Workspace W, uint32_t npad) {
-    uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t nh = W.counters[0];
-    uint32_t which = job >= npad;
-    uint32_t slot = which ? job - npad : job;
-    if (slot >= nh) return;
-    const RepDesc d = W.desc[W.hlist[slot]];
-    const uint8_t *seeds = d.base + 49;  // meas_seed | proof1_seed | jr_blind | proof2_seed
-    uint8_t agg = (uint8_t)d.role;
-    Sponge s;
-    if (!which) {
-        s.init_xof(P.alg_id, DST_MEAS, seeds);
-        s.absorb_byte(agg);
-        s.finalize();
-        xof_emit(s, const_cast<uint8_t *>(d.meas), P.input_len);
-    } else {
-#pragma unroll 1
-        for (int t = 0; t < 2; t++) {
-            s.init_xof(P.alg_id, DST_PROOF, seeds + (t ? 48 : 16));
-            s.absorb_byte(agg);
-            s.finalize();
-            xof_emit(s, const_cast<uint8_t *>(t ? d.proof2 : d.proof1), P.proof_len);
-        }
-    }
-}
+// (the Helper expansion kernel lives in expand.hip: hipcc 7.2 crashes in its inliner when this
+// translation unit holds both sponge kernels)
 
 // ---------------------------------------------------------------------------------- hash ----
-// derive_joint_rand_seed (prio3.rs:482-493) with this aggregator's own part substituted at
-// index `role` (prio3.rs:2564-2578, 2651-2665 -- the query-rand seed reuses DST_JR_SEED).
-__device__ __forceinline__ F128 derive_seed(const Prio3Dev &P, Sponge &s, const uint8_t *parts, uint32_t role,
-                                            const F128 &own) {
-    s.init_xof(P.alg_id, DST_JR_SEED, 0ull, 0ull);
-    if (role == 0) { s.absorb_f(own); s.absorb(parts + 16, 16); }
-    else { s.absorb(parts, 16); s.absorb_f(own); }
-    return s.into_seed();
-}
-
-// Job A (lanes [0, npad)): joint randomness, query randomness, barycentric weights.
-// Job B (lanes [npad, 2 npad)): public-parts hash, RLC coefficients, testing id.
+// Job A (lanes [0, npad)): six sponges -- own joint-rand part (prio3.rs:2543-2555), joint-rand
+//   seed (derive_joint_rand_seed :482-493 with the own part substituted, :2564-2578), joint
+//   randomness (:2580-2585), own query-rand part (:2610-2642), query-rand seed (:2651-2665, which
+//   reuses DST_JR_SEED), query randomness (:2667-2672) -- then the barycentric weights.
+// Job B (lanes [npad, 2 npad)): hash of the public parts (:2808-2840), RLC coefficients
+//   (:2859-2862), testing id (main.rs:51).
+// All sponges of a lane go through one loop body; a wave-uniform switch picks the inputs.
 __global__ void __launch_bounds__(256) k_hash(Prio3Dev P, Workspace W, uint32_t n, uint32_t npad, uint64_t vk0,
                                               uint64_t vk1, const uint8_t *aes_rk, uint8_t *testing_ids,
                                               int32_t *status) {
@@ -162,32 +130,61 @@ __global__ void __launch_bounds__(256) k_hash(Prio3Dev P, Workspace W, uint32_t 
     const uint8_t *pp = d.tail + 40;
     const uint8_t *qr_blind = pp + 32ull * P.verifier_len;
     const uint8_t *nonce = qr_blind + 16;
+    const uint32_t njr = 2 * P.jr_len;
+    uint8_t *own = reinterpret_cast<uint8_t *>(&sc->own);
     Sponge s;
+    F128 sd = f_zero();
+    const uint32_t nst = which ? 3 : 6;
+#pragma unroll 1
+    for (uint32_t stg = 0; stg < nst; stg++) {
+        uint32_t usage = 0, l1 = 0, l2 = 0, l3 = 0, emit_n = 0;
+        uint64_t k0 = 0, k1 = 0;
+        const uint8_t *p1 = nullptr, *p2 = nullptr, *p3 = nullptr;
+        uint8_t *emit_p = nullptr;
+        switch (__builtin_amdgcn_readfirstlane(which * 8 + stg)) {
+        case 0:  // own joint-rand part: XOF(blind, 7) . [agg_id] . nonce . enc(meas)
+            usage = DST_JR_PART; k0 = ld64(d.jr_blind); k1 = ld64(d.jr_blind + 8);
+            p1 = d.base + 48; l1 = 1; p2 = nonce; l2 = 16; p3 = d.meas; l3 = 16u * P.input_len;
+            break;
+        case 1:  // joint-rand seed over the parts, own part at index role
+        case 4: {
+            const uint8_t *parts = stg == 1 ? ps_parts : ps2_parts;
+            usage = DST_JR_SEED; l1 = 16; l2 = 16;
+            if (d.role == 0) { p1 = own; p2 = parts + 16; } else { p1 = parts; p2 = own; }
+            break;
+        }
+        case 2: usage = DST_JOINT_RAND; k0 = sd.lo; k1 = sd.hi; emit_n = njr; emit_p = reinterpret_cast<uint8_t *>(sc->jr); break;
+        case 3:  // own query-rand part: XOF(blind, 8) . enc(jr_fused) . enc(proof1) . enc(proof2)
+            usage = DST_QR_PART; k0 = ld64(qr_blind); k1 = ld64(qr_blind + 8);
+            p1 = reinterpret_cast<const uint8_t *>(sc->jr); l1 = 16 * njr;
+            p2 = d.proof1; l2 = 16u * P.proof_len; p3 = d.proof2; l3 = 16u * P.proof_len;
+            break;
+        case 5: usage = DST_QUERY_RAND; k0 = sd.lo; k1 = sd.hi; emit_n = 2; emit_p = reinterpret_cast<uint8_t *>(sc->qr); break;
+        case 8:  // hash of the public parts: XOF(0, 10) . parts . parts2 . enc(pp0) . enc(pp1)
+            usage = DST_HASH; p1 = ps_parts; l1 = 32; p2 = ps2_parts; l2 = 32; p3 = pp; l3 = 32u * P.verifier_len;
+            break;
+        case 9: usage = DST_HASH; k0 = sd.lo; k1 = sd.hi; emit_n = 1; emit_p = reinterpret_cast<uint8_t *>(&sc->hash); break;
+        default:  // 10: RLC coefficients; only the first verifier_len + 5 are consumed (:2865-2871)
+            usage = DST_RLC; k0 = vk0; k1 = vk1; p1 = nonce; l1 = 16;
+            emit_n = P.verifier_len + 5; emit_p = reinterpret_cast<uint8_t *>(W.rlc + (uint64_t)i * (P.verifier_len + 5));
+            break;
+        }
+        s.init_xof(P.alg_id, usage, k0, k1);
+        s.absorb3(p1, l1, p2, l2, p3, l3);
+        s.finalize();
+        if (emit_n) {
+            xof_emit(s, emit_p, emit_n);
+        } else {
+            sd = F128{s.st[0], s.st[1]};          // Xof::into_seed
+            if (!which && (stg == 0 || stg == 3)) {
+                // the locally computed part vs the one in the public share (prio3.rs:2790-2805)
+                const uint8_t *theirs = (stg == 0 ? ps_parts : ps2_parts) + 16 * d.role;
+                sc->rand_diff[stg == 3] = !f_eq(sd, ld128(theirs));
+                st128(own, sd);
+            }
+        }
+    }
     if (!which) {
-        // own joint-rand part: XOF(blind, dst 7) . [agg_id] . nonce . enc(meas)   (prio3.rs:2543-2555)
-        s.init_xof(P.alg_id, DST_JR_PART, d.jr_blind);
-        s.absorb_byte((uint8_t)d.role);
-        s.absorb(nonce, 16);
-        s.absorb(d.meas, 16u * P.input_len);
-        F128 own_jr = s.into_seed();
-        sc->rand_diff[0] = !f_eq(own_jr, ld128(ps_parts + 16 * d.role));
-        F128 seed = derive_seed(P, s, ps_parts, d.role, own_jr);
-        uint32_t njr = 2 * P.jr_len;
-        s.init_xof(P.alg_id, DST_JOINT_RAND, seed.lo, seed.hi);
-        s.finalize();
-        xof_emit(s, reinterpret_cast<uint8_t *>(sc->jr), njr);
-        // own query-rand part: XOF(blind, dst 8) . enc(jr_fused) . enc(proof1) . enc(proof2)  (:2610-2642)
-        s.init_xof(P.alg_id, DST_QR_PART, qr_blind);
-        s.absorb(reinterpret_cast<const uint8_t *>(sc->jr), 16 * njr);
-        s.absorb(d.proof1, 16u * P.proof_len);
-        s.absorb(d.proof2, 16u * P.proof_len);
-        F128 own_qr = s.into_seed();
-        sc->rand_diff[1] = !f_eq(own_qr, ld128(ps2_parts + 16 * d.role));
-        seed = derive_seed(P, s, ps2_parts, d.role, own_qr);
-        s.init_xof(P.alg_id, DST_QUERY_RAND, seed.lo, seed.hi);
-        s.finalize();
-        xof_emit(s, reinterpret_cast<uint8_t *>(sc->qr), 2);
-
         // flp.rs:413-419 for both runs: r^m == 1 is FlpError::Query
         F128 r1 = sc->qr[0], r = sc->qr[1];
         F128 r1m = f_sqr_n(r1, P.log2m), rm = f_sqr_n(r, P.log2m);
@@ -210,21 +207,6 @@ __global__ void __launch_bounds__(256) k_hash(Prio3Dev P, Workspace W, uint32_t 
             L[j] = f_mul(f_mul(k, w), dinv);
         }
     } else {
-        // hash of the public parts (prio3.rs:2808-2840): XOF(0, dst 10) . parts . parts2 . enc(pp0) . enc(pp1)
-        s.init_xof(P.alg_id, DST_HASH, 0ull, 0ull);
-        s.absorb(ps_parts, 32);
-        s.absorb(ps2_parts, 32);
-        s.absorb(pp, 32u * P.verifier_len);
-        F128 seed = s.into_seed();
-        s.init_xof(P.alg_id, DST_HASH, seed.lo, seed.hi);
-        s.finalize();
-        xof_emit(s, reinterpret_cast<uint8_t *>(&sc->hash), 1);
-        // RLC coefficients (prio3.rs:2859-2862); only the first verifier_len + 5 are consumed (:2865-2871)
-        s.init_xof(P.alg_id, DST_RLC, vk0, vk1);
-        s.absorb(nonce, 16);
-        s.finalize();
-        xof_emit(s, reinterpret_cast<uint8_t *>(W.rlc + (uint64_t)i * (P.verifier_len + 5)), P.verifier_len + 5);
-
         // testing id: AES128_vk(client_id.to_le_bytes()) (main.rs:51, common/src/prg.rs:650-655)
         const uint8_t *sbox = aes_rk + 176;
         uint8_t st[16], t[16];
@@ -488,7 +470,7 @@ __global__ void k_test_f128(const F128 *a, const F128 *b, F128 *out, uint32_t n,
     out[i] = r;
 }
 // XofShake128::seed_stream(seed, dst(alg_id, usage), binder).into_field_vec(n) per lane
-__global__ void k_test_xof(const uint8_t *seeds, uint32_t alg_id, uint32_t usage, const uint8_t *binder,
+__global__ void __launch_bounds__(64) k_test_xof(const uint8_t *seeds, uint32_t alg_id, uint32_t usage, const uint8_t *binder,
                            uint32_t binder_len, uint32_t n_elems, uint8_t *out, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

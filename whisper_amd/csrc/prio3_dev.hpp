@@ -51,6 +51,7 @@ struct RepScal {
     F128 jr[4];     // joint_rand_fused (2 * jr_len used)
     F128 qr[2];     // query_rand_fused
     F128 hash;      // hash of the public parts as a field element
+    F128 own;       // this aggregator's joint-rand / query-rand part while its seed is derived
     uint32_t rand_diff[2];
     uint32_t pad[2];
 };
