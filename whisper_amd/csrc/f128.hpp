@@ -40,48 +40,108 @@ WH_HD bool f_eq(const F128 &a, const F128 &b) { return a.lo == b.lo && a.hi == b
 WH_HD bool f_in_range(uint64_t lo, uint64_t hi) { return hi < P_HI || (hi == P_HI && lo < P_LO); }
 
 WH_HD F128 f_add(const F128 &a, const F128 &b) {
-    u128 x = f_u(a), y = f_u(b);
-    u128 s = x + y;
-    bool carry = s < x;
-    if (carry || s >= f_p()) s -= f_p();
-    return f_make(s);
+    uint64_t lo = a.lo + b.lo;
+    uint64_t c = lo < a.lo;
+    uint64_t hi = a.hi + b.hi;
+    uint64_t c1 = hi < a.hi;
+    hi += c;
+    uint64_t carry = c1 | (hi < c);
+    // a + b < 2p, so one subtraction of p = (2^64 - 28) 2^64 + 1 is enough
+    if (carry || hi > P_HI || (hi == P_HI && lo >= P_LO)) {
+        uint64_t bw = lo == 0;
+        lo -= 1;
+        hi = hi + 28u - bw;
+    }
+    return F128{lo, hi};
 }
 WH_HD F128 f_sub(const F128 &a, const F128 &b) {
-    u128 x = f_u(a), y = f_u(b);
-    u128 d = x - y;
-    if (x < y) d += f_p();
-    return f_make(d);
+    uint64_t lo = a.lo - b.lo;
+    uint64_t b1 = a.lo < b.lo;
+    uint64_t hi = a.hi - b.hi;
+    uint64_t b2 = a.hi < b.hi;
+    uint64_t borrow = b2 | (hi < b1);
+    hi -= b1;
+    if (borrow) {
+        lo += 1;
+        hi = hi - 28u + (lo == 0);
+    }
+    return F128{lo, hi};
 }
-WH_HD F128 f_neg(const F128 &a) { return f_is_zero(a) ? a : f_make(f_p() - f_u(a)); }
+WH_HD F128 f_neg(const F128 &a) { return f_sub(F128{0, 0}, a); }
 
-// reduce z3:z2:z1:z0 (256 bits) to the canonical residue
+// Reduce a 256-bit value given as eight 32-bit limbs (little endian) to the canonical residue.
+// Written on 32/64-bit integers only so that hipcc lowers it to v_mad_u64_u32 and 64-bit adds
+// (no 128-bit temporaries, no carry chains through VCC).
+//   value = (Z0 - Z2 - 28 Z3) + 2^64 (Z1 + 28 Z2 + 783 Z3),   Zk = z[2k] + 2^32 z[2k+1]
+WH_HD F128 f_reduce_limbs(uint32_t z0, uint32_t z1, uint32_t z2, uint32_t z3, uint32_t z4, uint32_t z5,
+                          uint32_t z6, uint32_t z7) {
+    // A = Z1 + 28 Z2 + 783 Z3  -> limbs a0, a1 and a small top part a2 < 2^10
+    uint64_t t = (uint64_t)z4 * 28u + z2;
+    t = (uint64_t)z6 * 783u + t;
+    uint32_t a0 = (uint32_t)t;
+    t = (uint64_t)z5 * 28u + (t >> 32);
+    t += z3;
+    t = (uint64_t)z7 * 783u + t;
+    uint32_t a1 = (uint32_t)t, a2 = (uint32_t)(t >> 32);
+    // a2 2^128 = a2 (28 2^64 - 1): fold into A (may carry once more) and into the negative part
+    uint64_t A = ((uint64_t)a1 << 32) | a0;
+    uint64_t A1 = A + (uint64_t)a2 * 28u;
+    uint32_t c2 = A1 < A;
+    A1 += c2 * 28u;                         // no further carry: after a wrap A1 < 2^15
+    // neg = Z2 + 28 Z3 + a2 + c2  (< 2^69): limbs n_lo (64 bits) and n2
+    t = (uint64_t)z6 * 28u + z4;
+    t += (uint64_t)a2 + c2;
+    uint32_t n0 = (uint32_t)t;
+    t = (uint64_t)z7 * 28u + (t >> 32);
+    t += z5;
+    uint64_t n_lo = ((uint64_t)(uint32_t)t << 32) | n0;
+    uint64_t n2 = t >> 32;
+    // R = (A1 2^64 + Z0) - neg  (mod 2^128), then one conditional +p or -p
+    uint64_t s_lo = ((uint64_t)z1 << 32) | z0;
+    uint64_t r_lo = s_lo - n_lo;
+    uint64_t b1 = s_lo < n_lo;
+    uint64_t sub_hi = n2 + b1;
+    uint64_t r_hi = A1 - sub_hi;
+    bool borrow = A1 < sub_hi;
+    if (borrow) {
+        // + p = + (2^128 - 28 2^64 + 1)
+        uint64_t lo = r_lo + 1;
+        uint64_t cy = lo == 0;
+        r_hi = r_hi - 28u + cy;
+        r_lo = lo;
+    } else if (r_hi > P_HI || (r_hi == P_HI && r_lo >= P_LO)) {
+        uint64_t bw = r_lo == 0;
+        r_lo -= 1;
+        r_hi = r_hi + 28u - bw;
+    }
+    return F128{r_lo, r_hi};
+}
 WH_HD F128 f_reduce256(uint64_t z0, uint64_t z1, uint64_t z2, uint64_t z3) {
-    // value = (z1 + 28 z2 + 783 z3) 2^64 + (z0 - z2 - 28 z3)
-    u128 A = (u128)z1 + (u128)z2 * 28u + (u128)z3 * 783u;  // < 2^74
-    uint64_t a_lo = (uint64_t)A, a_hi = (uint64_t)(A >> 64);  // a_hi < 2^10
-    // a_hi 2^128 = a_hi (28 2^64 - 1)
-    u128 A1 = (u128)a_lo + (u128)a_hi * 28u;
-    uint64_t c = (uint64_t)(A1 >> 64);  // 0 or 1
-    uint64_t a2 = (uint64_t)A1 + c * 28u;  // no further carry: if c then (uint64)A1 < 2^15
-    u128 neg = (u128)z2 + (u128)z3 * 28u + a_hi + c;  // < 2^69
-    u128 S = ((u128)a2 << 64) + z0;
-    if (S >= neg) S -= neg; else S = f_p() - (neg - S);
-    if (S >= f_p()) S -= f_p();
-    return f_make(S);
+    return f_reduce_limbs((uint32_t)z0, (uint32_t)(z0 >> 32), (uint32_t)z1, (uint32_t)(z1 >> 32), (uint32_t)z2,
+                          (uint32_t)(z2 >> 32), (uint32_t)z3, (uint32_t)(z3 >> 32));
 }
 
-WH_HD F128 f_mul(const F128 &a, const F128 &b) {
-    u128 p00 = (u128)a.lo * b.lo;
-    u128 p01 = (u128)a.lo * b.hi;
-    u128 p10 = (u128)a.hi * b.lo;
-    u128 p11 = (u128)a.hi * b.hi;
-    uint64_t z0 = (uint64_t)p00;
-    u128 t = (p00 >> 64) + (uint64_t)p01 + (uint64_t)p10;
-    uint64_t z1 = (uint64_t)t;
-    t = (t >> 64) + (p01 >> 64) + (p10 >> 64) + (uint64_t)p11;
-    uint64_t z2 = (uint64_t)t;
-    uint64_t z3 = (uint64_t)((t >> 64) + (p11 >> 64));
-    return f_reduce256(z0, z1, z2, z3);
+// Schoolbook 4 x 4 limbs, row by row: every step is t = a_i b_j + z + carry, which cannot
+// overflow 64 bits ((2^32-1)^2 + 2 (2^32-1) = 2^64 - 1).
+WH_HD F128 f_mul(const F128 &x, const F128 &y) {
+    const uint32_t a0 = (uint32_t)x.lo, a1 = (uint32_t)(x.lo >> 32), a2 = (uint32_t)x.hi, a3 = (uint32_t)(x.hi >> 32);
+    const uint32_t b0 = (uint32_t)y.lo, b1 = (uint32_t)(y.lo >> 32), b2 = (uint32_t)y.hi, b3 = (uint32_t)(y.hi >> 32);
+    uint64_t t;
+    uint32_t z0, z1, z2, z3, z4, z5, z6, z7;
+    t = (uint64_t)a0 * b0;                         z0 = (uint32_t)t;
+    t = (uint64_t)a0 * b1 + (t >> 32);             z1 = (uint32_t)t;
+    t = (uint64_t)a0 * b2 + (t >> 32);             z2 = (uint32_t)t;
+    t = (uint64_t)a0 * b3 + (t >> 32);             z3 = (uint32_t)t; z4 = (uint32_t)(t >> 32);
+#define WH_ROW(ai, zA, zB, zC, zD, zE)                                                         \
+    t = (uint64_t)ai * b0 + zA;                            zA = (uint32_t)t;                     \
+    t = (uint64_t)ai * b1 + zB + (t >> 32);                zB = (uint32_t)t;                     \
+    t = (uint64_t)ai * b2 + zC + (t >> 32);                zC = (uint32_t)t;                     \
+    t = (uint64_t)ai * b3 + zD + (t >> 32);                zD = (uint32_t)t; zE = (uint32_t)(t >> 32);
+    WH_ROW(a1, z1, z2, z3, z4, z5)
+    WH_ROW(a2, z2, z3, z4, z5, z6)
+    WH_ROW(a3, z3, z4, z5, z6, z7)
+#undef WH_ROW
+    return f_reduce_limbs(z0, z1, z2, z3, z4, z5, z6, z7);
 }
 WH_HD F128 f_sqr(const F128 &a) { return f_mul(a, a); }
 
