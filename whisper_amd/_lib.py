@@ -7,7 +7,8 @@ import os
 # copy instead of bringing a second HIP runtime into the process (the second one sees no GPU).
 import torch  # noqa: F401
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwhisper_gfx950.so")
+# WHISPER_GFX950_LIB selects another build of the same library (A/B runs of kernel variants)
+LIB_PATH = os.environ.get("WHISPER_GFX950_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwhisper_gfx950.so")
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         f"{LIB_PATH} is missing: build it with `make -C whisper_amd/csrc` (or __graft_entry__.build()); "
