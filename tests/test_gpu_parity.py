@@ -58,6 +58,9 @@ CASES = [
     ("histogram_4_2", (W.HISTOGRAM, 0, 4, 2), 8),
     ("histogram_11_3", (W.HISTOGRAM, 0, 11, 3), 8),
     ("histogram_128_64", (W.HISTOGRAM, 0, 128, 64), 20),
+    ("average_64", (W.AVERAGE, 64, 0, 0), 20),                     # AVG_BITS, bin-utils/src/lib.rs:34
+    ("average_8", (W.AVERAGE, 8, 0, 0), 6),
+    ("average_3", (W.AVERAGE, 3, 0, 0), 6),                        # m = 4
 ]
 
 
@@ -115,8 +118,10 @@ def test_prepare_and_aggregate_match_oracle(name, cfg, n):
         good = [i for i in range(n) if i not in bad]
         if circ == W.SUMVEC:
             want = [int(sum(int(meas[i][e]) for i in good)) for e in range(ln)]
-        else:
+        elif circ == W.HISTOGRAM:
             want = [sum(1 for i in good if int(meas[i][0]) == e) for e in range(ln)]
+        else:
+            want = [int(sum(int(meas[i][0]) for i in good))]
         assert total == want
     finally:
         vdaf.close()

@@ -226,7 +226,6 @@ int32_t wh_prio3_prepare_batch_dev(wh_ctx *c, const uint8_t verify_key[16], cons
                                    const uint64_t *d_offsets, uint64_t n, uint8_t *d_tags, uint8_t *d_ids,
                                    int32_t *d_status) {
     if (!c || !verify_key || (n && (!d_blob || !d_offsets || !d_tags || !d_ids || !d_status))) return WH_ERR_PARAM;
-    if (c->params.circuit == WH_AVERAGE) return WH_ERR_UNSUPPORTED;
     if (n > 0xfffffff0ull) return WH_ERR_PARAM;
     HIPCHK(c, hipSetDevice(c->device));
     const HostSizes &z = c->z;
@@ -246,7 +245,8 @@ int32_t wh_prio3_prepare_batch_dev(wh_ctx *c, const uint8_t verify_key[16], cons
     memcpy(&vk0, verify_key, 8); memcpy(&vk1, verify_key + 8, 8);
     c->n_last = n;
     c->d_status_last = d_status;
-    const size_t lds = 4 * 2 * (size_t)(z.calls + 1) * sizeof(F128);
+    const bool polyeval = c->params.circuit == WH_AVERAGE;
+    const size_t lds = polyeval ? 4 * (size_t)z.m * sizeof(F128) : 4 * 2 * (size_t)(z.calls + 1) * sizeof(F128);
     for (uint64_t base = 0; base < n; base += c->cap) {
         const uint32_t nb = (uint32_t)((n - base < c->cap) ? n - base : c->cap);
         const uint32_t npad = (nb + 255) / 256 * 256;
@@ -260,7 +260,7 @@ int32_t wh_prio3_prepare_batch_dev(wh_ctx *c, const uint8_t verify_key[16], cons
         hipLaunchKernelGGL(k_hash, dim3(2 * npad / 256), dim3(256), 0, c->stream, c->P, c->W, nb, npad, vk0, vk1,
                            c->d_aes, d_ids + 16 * base, d_status + base); }
         { KTimer t_(c, WH_K_QUERY);
-        hipLaunchKernelGGL(k_query_psum, dim3((nb + 3) / 4), dim3(256), lds, c->stream, c->P, c->W, nb,
+        hipLaunchKernelGGL(polyeval ? k_query_polyeval : k_query_psum, dim3((nb + 3) / 4), dim3(256), lds, c->stream, c->P, c->W, nb,
                            d_tags + 16 * base, reinterpret_cast<uint8_t *>(c->d_out_shares + base * z.output_len),
                            d_status + base); }
         HIPCHK(c, hipGetLastError());

@@ -396,6 +396,125 @@ __global__ void __launch_bounds__(256) k_query_psum(Prio3Dev P, Workspace W, uin
     }
 }
 
+// Average (Sum) circuit: one PolyEval(x^2 - x) gadget of arity 1 called once per input bit
+// (types.rs:241-313, call_gadget_on_vec_entries :686-698, gadgets.rs:185-188).  One wavefront per
+// report; m <= 128 so a wave holds the whole problem.
+//   v[0] = sum_{i=1..calls} rho^i G(w^i)       -- G at the call points by folding G to m
+//                                                 coefficients and one m-point NTT in LDS
+//   v[1] = L_0 proof[0] + sum_j L_j x_{j-1}    -- the single wire polynomial at r
+//   v[2] = G(r)
+// decide on a public proof: pp[0] == 0 and pp[1]^2 - pp[1] == pp[2].
+__global__ void __launch_bounds__(256) k_query_polyeval(Prio3Dev P, Workspace W, uint32_t n, uint8_t *tags,
+                                                        uint8_t *out_shares, int32_t *status) {
+    extern __shared__ F128 lds[];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t i = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (i >= n) return;
+    uint8_t *tag_out = tags + 16ull * i;
+    F128 *out_row = reinterpret_cast<F128 *>(out_shares) + (uint64_t)i;   // output_len == 1
+    if (status[i] != ST_OK) {
+        if (lane == 0) { out_row[0] = f_zero(); st128(tag_out, f_zero()); }
+        return;
+    }
+    const uint32_t m = P.m;
+    F128 *buf = lds + (uint64_t)wave * m;
+    const RepDesc d = W.desc[i];
+    const RepScal *sc = &W.scal[i];
+    const uint8_t *pp0 = d.tail + 40, *pp1 = pp0 + 16ull * P.verifier_len;
+    const F128 *rlc = W.rlc + (uint64_t)i * (P.verifier_len + 5);
+    const F128 *Lg = W.weights + (uint64_t)i * P.n_weights;
+    const F128 r = sc->qr[1], rho = sc->jr[P.jr_len];
+    const bool leader = d.role == 0;
+    uint32_t bad = 0;
+
+    if (leader)
+        for (uint32_t e = lane; e < P.proof_len; e += 64) {
+            F128 v = ld128(d.proof1 + 16ull * e);
+            bad |= !f_in_range(v.lo, v.hi);
+        }
+    // G = proof2[1 ..]: G(r), and G folded mod (X^m - 1) into LDS in bit-reversed order
+    const uint8_t *G = d.proof2 + 16ull * P.arity;
+    F128 g_at_r = f_zero();
+    {
+        F128 rpow = f_pow_u32(r, lane), r64 = f_sqr_n(r, 6);
+        for (uint32_t e = lane; e < P.gpoly_len; e += 64) {
+            F128 c = ld128(G + 16ull * e);
+            bad |= !f_in_range(c.lo, c.hi);
+            g_at_r = f_add(g_at_r, f_mul(c, rpow));
+            rpow = f_mul(rpow, r64);
+        }
+    }
+    g_at_r = wave_sum(g_at_r);
+    for (uint32_t e = lane; e < m; e += 64) {
+        F128 c = ld128(G + 16ull * e);
+        if (e + m < P.gpoly_len) c = f_add(c, ld128(G + 16ull * (e + m)));
+        buf[__brev(e) >> (32 - P.log2m)] = c;
+    }
+    // in-place radix-2 NTT, one butterfly per lane and stage (m / 2 <= 64 butterflies)
+    for (uint32_t l = 1; l <= P.log2m; l++) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t half = 1u << (l - 1);
+        if (lane < (m >> 1)) {
+            uint32_t k = lane & (half - 1), base = ((lane >> (l - 1)) << l) + k;
+            F128 u = buf[base], v = f_mul(buf[base + half], P.omega[k << (P.log2m - l)]);
+            buf[base] = f_add(u, v);
+            buf[base + half] = f_sub(u, v);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    F128 v0 = f_zero(), v1 = f_zero();
+    for (uint32_t j = 1 + lane; j <= P.calls; j += 64) {
+        F128 x = ld128(d.meas + 16ull * (j - 1));
+        bad |= !f_in_range(x.lo, x.hi);
+        v0 = f_add(v0, f_mul(f_pow_u32(rho, j), buf[j]));
+        v1 = f_add(v1, f_mul(Lg[j], x));
+    }
+    v0 = wave_sum(v0);
+    F128 seed0 = ld128(d.proof2);
+    bad |= !f_in_range(seed0.lo, seed0.hi);
+    v1 = f_add(wave_sum(v1), f_mul(Lg[0], seed0));
+
+    // truncate: sum_l 2^l x_l (field.rs:256-269)
+    F128 out = f_zero();
+    for (uint32_t l = lane; l < P.bits; l += 64) {
+        F128 w = l < 64 ? F128{1ull << l, 0} : F128{0, 1ull << (l - 64)};
+        out = f_add(out, f_mul(w, ld128(d.meas + 16ull * l)));
+    }
+    out = wave_sum(out);
+
+    F128 tag = f_zero();
+    if (lane == 0) {
+        F128 ver[3] = {v0, v1, g_at_r};
+        F128 dec[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const uint8_t *pp = t ? pp1 : pp0;
+            F128 a = ld128(pp), b = ld128(pp + 16), c = ld128(pp + 32);
+            bad |= !f_in_range(a.lo, a.hi) | !f_in_range(b.lo, b.hi) | !f_in_range(c.lo, c.hi);
+            bool ok = f_is_zero(a) && f_eq(f_sub(f_sqr(b), b), c);
+            dec[t] = ok ? f_zero() : f_one();
+        }
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            F128 dv = leader ? f_sub(ver[e], ld128(pp1 + 16 * e)) : ver[e];
+            tag = f_add(tag, f_mul(rlc[e], dv));
+        }
+        tag = f_add(tag, f_mul(rlc[3], dec[0]));
+        tag = f_add(tag, f_mul(rlc[4], dec[1]));
+        if (sc->rand_diff[0]) tag = f_add(tag, rlc[5]);
+        if (sc->rand_diff[1]) tag = f_add(tag, rlc[6]);
+        tag = f_add(tag, f_mul(rlc[7], leader ? f_neg(sc->hash) : sc->hash));
+    }
+    bad = wave_or(bad);
+    if (lane == 0) {
+        if (bad) { status[i] = ST_ERR_MODULUS; tag = f_zero(); out = f_zero(); }
+        out_row[0] = out;
+        st128(tag_out, leader ? tag : f_neg(tag));
+    }
+}
+
 // ----------------------------------------------------------------------------- aggregate ----
 // Aggregatable::merge over the kept reports (vdaf.rs:658-676, main.rs:108-118): column sums
 // of out_shares[n][len] mod p.  Pure HBM streaming: 16 B per (report, element).  Each block
