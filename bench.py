@@ -22,6 +22,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import whisper_amd as W  # noqa: E402
+from whisper_amd.dist import all_gather_partials  # noqa: E402
 
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from common import VK, make_reports  # noqa: E402  (deterministic synthetic clients; no oracle involved)
@@ -104,7 +105,6 @@ def main():
     keep[:: 1000] = 0                      # ~0.1 % of the clients flagged by the group test
     d_keep = torch.from_numpy(keep).to(dev)
     d_agg = torch.zeros(16 * s.output_len, dtype=torch.uint8, device=dev)
-    d_gather = torch.zeros(world * 16 * s.output_len, dtype=torch.uint8, device=dev)
     d_total = torch.zeros(16 * s.output_len, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 
@@ -115,9 +115,10 @@ def main():
         vdaf.prepare_batch_dev(VK, d_blob.data_ptr(), d_off.data_ptr(), n, d_tags.data_ptr(), d_ids.data_ptr(), d_status.data_ptr())
         vdaf.aggregate_dev(d_keep.data_ptr(), d_agg.data_ptr())
         if world > 1:
+            # RCCL all-gather of the raw limbs on the context stream, then the on-GPU mod-p row sum
             with torch.cuda.stream(ext):
-                dist.all_gather_into_tensor(d_gather, d_agg)
-            vdaf.sum_rows_dev(d_gather.data_ptr(), world, s.output_len, None, d_total.data_ptr())
+                rows = all_gather_partials(d_agg)
+            vdaf.sum_rows_dev(rows.data_ptr(), world, s.output_len, None, d_total.data_ptr())
 
     def barrier():
         if world > 1:
