@@ -158,6 +158,19 @@ def main():
     avg_ms = kernels[dom]["ms_per_step"] / launches
     bytes_per_launch = per[dom] / launches
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+    # HBM traffic of the same kernel from the PMC passes committed under profiles/ (collected with
+    # rocprofv3 --pmc in separate runs; only valid for the workload and size it was taken on)
+    traffic, traffic_src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        ent = pmc.get(args.workload)
+        if ent and ent["reports_per_gpu"] == n and ("k_" + dom) in ent["kernels"]:
+            kk = ent["kernels"]["k_" + dom]
+            traffic = (kk["fetch_bytes"] + kk["write_bytes"]) * (1.0 / launches if launches > 1 else 1.0)
+            traffic_src = pmc["source"]
+    except (OSError, ValueError, KeyError):
+        pass
     # SHAKE128 work of the step, for the VALU side of the story
     def perms(role):
         IL, PL, VL = s.input_len, s.proof_len, s.verifier_len
@@ -186,7 +199,7 @@ def main():
                        "parallelism": f"reports sharded over {world} GPU(s); all-gather + mod-p reduce of partial aggregates",
                        "status_nonzero": n_bad_status, "client_gen_s": round(t_gen, 2)},
             "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": avg_ms, "alg_bytes_per_launch": bytes_per_launch,
                          "note": "the verify kernels are integer-VALU bound (SHAKE128 + Field128), not HBM bound; see valu"},
             "valu": {"keccak_f1600_per_step": total_perms,
