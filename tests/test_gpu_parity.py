@@ -37,6 +37,19 @@ def test_field_ops_bit_exact(small_ctx):
         got = O.f_dec(out[16 * i:16 * i + 16])
         assert got == (pow(a[i], p - 2, p) if a[i] else 0)
         assert got == O.f_inv(a[i])
+    # the lazy dot product (f128.hpp): one term, and the maximum number of terms with the largest
+    # limbs (non-canonical all-ones inputs included), must reduce to the same element
+    ones = (2**128 - 1).to_bytes(16, "little")
+    a2 = a[:2040] + [2**128 - 1] * 8
+    b2 = b[:2040] + [2**128 - 1, p - 1, 2**104 - 1, 1, 0, 2**26 - 1, 2**52, 2**127]
+    ab2 = np.frombuffer(b"".join(x.to_bytes(16, "little") for x in a2), np.uint8)
+    bb2 = np.frombuffer(b"".join(x.to_bytes(16, "little") for x in b2), np.uint8)
+    out = small_ctx.test_f128_op(4, ab2, bb2).tobytes()
+    assert out == b"".join(O.f_enc(x * y % p) for x, y in zip(a2, b2))
+    out = small_ctx.test_f128_op(5, ab2, bb2).tobytes()
+    assert out == b"".join(O.f_enc(512 * x * y % p) for x, y in zip(a2, b2))
+    out = small_ctx.test_f128_op(6, ab2).tobytes()
+    assert out == b"".join(O.f_enc((2**32 - 1) * x % p) for x in a2)
 
 
 @pytest.mark.parametrize("n_elems,binder", [(1, b""), (2, b"\x01"), (10, b"x" * 16), (11, b""), (21, b"abc"), (22, b"q" * 143),
@@ -55,6 +68,10 @@ CASES = [
     ("sumvec_cfg1_16_128_64", (W.SUMVEC, 16, 128, 64), 70),       # configs/prio3-server-alice.json
     ("sumvec_chunk128", (W.SUMVEC, 16, 64, 128), 6),               # chunk wider than a wavefront
     ("sumvec_chunk5_len40", (W.SUMVEC, 8, 40, 5), 5),              # many calls: m = 128
+    ("sumvec_chunk200", (W.SUMVEC, 4, 150, 200), 5),               # two slot blocks per wave
+    ("sumvec_calls600", (W.SUMVEC, 1, 1200, 2), 4),                # lazy sums flushed mid-way
+    ("sumvec_bits33", (W.SUMVEC, 33, 4, 12), 4),                   # truncate by doubling
+    ("histogram_chunk130", (W.HISTOGRAM, 0, 300, 130), 5),
     ("histogram_4_2", (W.HISTOGRAM, 0, 4, 2), 8),
     ("histogram_11_3", (W.HISTOGRAM, 0, 11, 3), 8),
     ("histogram_128_64", (W.HISTOGRAM, 0, 128, 64), 20),
@@ -88,6 +105,7 @@ def test_prepare_and_aggregate_match_oracle(name, cfg, n):
     x = bytearray(alice[1]); x[nq_off:nq_off + 8] = (p.verifier_len - 1).to_bytes(8, "big"); a_err.append(bytes(x))
     a_err.append(alice[0] + b"\x00" * 7)                          # trailing bytes are not looked at
     x = bytearray(alice[0]); x[60] ^= 0x40; a_err.append(bytes(x))  # still canonical, wrong share -> bad tag
+    x = bytearray(alice[0]); x[49:65] = b"\x00" * 12 + b"\xff" * 4; a_err.append(bytes(x))   # top word all ones, < p
 
     vdaf = W.Prio3(p)
     try:

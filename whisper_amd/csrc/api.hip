@@ -111,7 +111,7 @@ void aes_tables(const uint8_t key[16], uint8_t out[432]) {
 int32_t alloc_workspace(wh_ctx *c, uint64_t cap) {
     if (cap <= c->cap) return WH_OK;
     Workspace &W = c->W;
-    void *ptrs[] = {W.desc, W.scal, W.weights, W.rlc, W.hrows, W.hlist, W.counters};
+    void *ptrs[] = {W.desc, W.scal, W.weights, W.wlimbs, W.pows, W.rlc, W.hrows, W.hlist, W.counters};
     for (void *p : ptrs) if (p) HIPCHK(c, hipFree(p));
     W = Workspace{};
     c->cap = 0;
@@ -121,6 +121,10 @@ int32_t alloc_workspace(wh_ctx *c, uint64_t cap) {
     HIPCHK(c, hipMalloc((void **)&W.scal, cap * sizeof(RepScal)));
     HIPCHK(c, hipMalloc((void **)&W.weights, cap * (uint64_t)(z.calls + 1) * sizeof(F128)));
     HIPCHK(c, hipMalloc((void **)&W.rlc, cap * (uint64_t)(z.verifier_len + 5) * sizeof(F128)));
+    if (c->params.circuit != WH_AVERAGE) {
+        HIPCHK(c, hipMalloc((void **)&W.wlimbs, cap * (uint64_t)z.calls * 48));
+        HIPCHK(c, hipMalloc((void **)&W.pows, cap * sizeof(RepPow)));
+    }
     HIPCHK(c, hipMalloc((void **)&W.hrows, cap * W.hrow_bytes));
     HIPCHK(c, hipMalloc((void **)&W.hlist, cap * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc((void **)&W.counters, 64));
@@ -205,7 +209,7 @@ void wh_ctx_destroy(wh_ctx *c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_omega, c->d_stab, c->d_aes, c->d_out_shares, c->d_status_own, c->d_keep_eff, c->d_partials,
-                    c->d_blob, c->d_offsets, c->d_tags, c->d_ids, c->W.desc, c->W.scal, c->W.weights, c->W.rlc,
+                    c->d_blob, c->d_offsets, c->d_tags, c->d_ids, c->W.desc, c->W.scal, c->W.weights, c->W.wlimbs, c->W.pows, c->W.rlc,
                     c->W.hrows, c->W.hlist, c->W.counters};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -246,7 +250,16 @@ int32_t wh_prio3_prepare_batch_dev(wh_ctx *c, const uint8_t verify_key[16], cons
     c->n_last = n;
     c->d_status_last = d_status;
     const bool polyeval = c->params.circuit == WH_AVERAGE;
-    const size_t lds = polyeval ? 4 * (size_t)z.m * sizeof(F128) : 4 * 2 * (size_t)(z.calls + 1) * sizeof(F128);
+    // query launch shape.  Average: four reports (wavefronts) per workgroup.  ParallelSum circuits:
+    // one workgroup per report, one wavefront per 64 gadget slots (at most four), 48 B of weight
+    // limbs per gadget call in LDS plus the hand-over area.
+    const uint32_t qwaves = polyeval ? 4 : (c->params.chunk <= 64 ? 1 : (c->params.chunk <= 128 ? 2 : 4));
+    const size_t lds = polyeval ? 4 * (size_t)z.m * sizeof(F128)
+                                : 48 * (size_t)z.calls + sizeof(QueryShared) + qwaves * (size_t)QT_STAGE_U4 * 16;
+    if (lds > 64 * 1024) { c->err = "circuit has too many gadget calls for the query kernel's LDS rows"; return WH_ERR_UNSUPPORTED; }
+    typedef void (*query_fn)(Prio3Dev, Workspace, uint32_t, uint8_t *, uint8_t *, int32_t *);
+    const query_fn qfn = polyeval ? k_query_polyeval
+                                  : (c->params.circuit == WH_HISTOGRAM ? k_query_psum<true> : k_query_psum<false>);
     for (uint64_t base = 0; base < n; base += c->cap) {
         const uint32_t nb = (uint32_t)((n - base < c->cap) ? n - base : c->cap);
         const uint32_t npad = (nb + 255) / 256 * 256;
@@ -260,7 +273,7 @@ int32_t wh_prio3_prepare_batch_dev(wh_ctx *c, const uint8_t verify_key[16], cons
         hipLaunchKernelGGL(k_hash, dim3(2 * npad / 256), dim3(256), 0, c->stream, c->P, c->W, nb, npad, vk0, vk1,
                            c->d_aes, d_ids + 16 * base, d_status + base); }
         { KTimer t_(c, WH_K_QUERY);
-        hipLaunchKernelGGL(polyeval ? k_query_polyeval : k_query_psum, dim3((nb + 3) / 4), dim3(256), lds, c->stream, c->P, c->W, nb,
+        hipLaunchKernelGGL(qfn, dim3(polyeval ? (nb + 3) / 4 : nb), dim3(64 * qwaves), lds, c->stream, c->P, c->W, nb,
                            d_tags + 16 * base, reinterpret_cast<uint8_t *>(c->d_out_shares + base * z.output_len),
                            d_status + base); }
         HIPCHK(c, hipGetLastError());

@@ -174,4 +174,89 @@ WH_HD F128 f_inv(const F128 &x) {
     return r;
 }
 
+// ---- lazy dot products ------------------------------------------------------------------
+// sum_t x_t * w_t without reducing per term: both operands are cut into five 26-bit limbs and
+// the 25 partial products of a term are added into nine 64-bit column sums (one
+// v_mad_u64_u32 each, no carries).  A product is < 2^52 and a column receives at most five per
+// term, so LAZY_MAX_TERMS terms fit in 64 bits; f_lazy_reduce then yields the same canonical
+// element as the term-by-term f_add(f_mul()) chain.
+constexpr uint32_t M26 = (1u << 26) - 1;
+constexpr uint32_t LAZY_MAX_TERMS = 512;
+struct Lazy {
+    uint64_t c[9];
+};
+WH_HD void f_split26(const F128 &x, uint32_t (&o)[5]) {
+    o[0] = (uint32_t)x.lo & M26;
+    o[1] = (uint32_t)(x.lo >> 26) & M26;
+    o[2] = (uint32_t)((x.hi << 12) | (x.lo >> 52)) & M26;
+    o[3] = (uint32_t)(x.hi >> 14) & M26;
+    o[4] = (uint32_t)(x.hi >> 40);
+}
+WH_HD void f_lazy_zero(Lazy &a) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) a.c[k] = 0;
+}
+// acc += a * b as one v_mad_u64_u32.  Written as an asm statement because the optimiser
+// otherwise sums the products of a column first and adds the running sum with a separate
+// 64-bit add (one extra instruction per column and term).
+WH_HD void mad_acc(uint64_t &acc, uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t carry_out;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(carry_out) : "v"(a), "v"(b));
+#else
+    acc += (uint64_t)a * b;
+#endif
+}
+WH_HD void f_lazy_mac(Lazy &a, const uint32_t (&x)[5], const uint32_t (&w)[5]) {
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+#pragma unroll
+        for (int j = 0; j < 5; j++) mad_acc(a.c[i + j], x[i], w[j]);
+}
+WH_HD F128 f_lazy_reduce(const Lazy &a) {
+    // carry the column sums into 26-bit digits l[0..10] (value < 2^271)
+    uint64_t l[11];
+    uint64_t t = a.c[0];
+    l[0] = t & M26;
+#pragma unroll
+    for (int k = 1; k < 9; k++) {
+        t = a.c[k] + (t >> 26);
+        l[k] = t & M26;
+    }
+    t >>= 26;
+    l[9] = t & M26;
+    l[10] = t >> 26;
+    // repack at 64-bit boundaries: digit k starts at bit 26 k
+    const uint64_t w0 = l[0] | (l[1] << 26) | (l[2] << 52);
+    const uint64_t w1 = (l[2] >> 12) | (l[3] << 14) | (l[4] << 40);
+    const uint64_t w2 = (l[4] >> 24) | (l[5] << 2) | (l[6] << 28) | (l[7] << 54);
+    const uint64_t w3 = (l[7] >> 10) | (l[8] << 16) | (l[9] << 42);
+    const uint64_t w4 = (l[9] >> 22) | (l[10] << 4);
+    // 2^256 = 21896 * 2^64 - 783 (mod p)
+    const F128 c256 = F128{0xfffffffffffffcf1ULL, 0x5587ULL};
+    return f_add(f_reduce256(w0, w1, w2, w3), f_mul(F128{w4, 0}, c256));
+}
+// sum of 128-bit values x_t * s_t with small multipliers (s_t < 2^31, sum of s_t < 2^32):
+// four 64-bit column sums over the 32-bit words of x
+struct LazySmall {
+    uint64_t c[4];
+};
+WH_HD void f_small_zero(LazySmall &a) { a.c[0] = a.c[1] = a.c[2] = a.c[3] = 0; }
+WH_HD void f_small_mac(LazySmall &a, const F128 &x, uint32_t s) {
+    a.c[0] += (uint64_t)(uint32_t)x.lo * s;
+    a.c[1] += (uint64_t)(uint32_t)(x.lo >> 32) * s;
+    a.c[2] += (uint64_t)(uint32_t)x.hi * s;
+    a.c[3] += (uint64_t)(uint32_t)(x.hi >> 32) * s;
+}
+WH_HD F128 f_small_reduce(const LazySmall &a) {
+    uint64_t t = a.c[0];
+    const uint32_t z0 = (uint32_t)t;
+    t = a.c[1] + (t >> 32);
+    const uint32_t z1 = (uint32_t)t;
+    t = a.c[2] + (t >> 32);
+    const uint32_t z2 = (uint32_t)t;
+    t = a.c[3] + (t >> 32);
+    return f_reduce_limbs(z0, z1, z2, (uint32_t)t, (uint32_t)(t >> 32), 0, 0, 0);
+}
+
 }  // namespace wh

@@ -24,6 +24,16 @@ namespace wh {
 // ------------------------------------------------------------------------------- helpers ----
 __device__ __forceinline__ uint64_t be64(const uint8_t *p) { return __builtin_bswap64(ld64(p)); }
 
+// 16-byte load from a pointer known to be in global memory (report bytes and workspace rows,
+// reached through descriptors the compiler cannot see through): global_load instead of
+// flat_load, so that loads issued ahead of their use are counted by vmcnt alone.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_unaligned __attribute__((aligned(1)));
+__device__ __forceinline__ F128 ld128g(const uint8_t *p) {
+    const u32x4 v = *(const __attribute__((address_space(1))) u32x4_unaligned *)p;
+    return F128{v.x | ((uint64_t)v.y << 32), v.z | ((uint64_t)v.w << 32)};
+}
+
 __device__ __forceinline__ F128 shfl_xor_f(const F128 &v, int mask) {
     F128 r;
     r.lo = __shfl_xor((unsigned long long)v.lo, mask, 64);
@@ -206,6 +216,40 @@ __global__ void __launch_bounds__(256) k_hash(Prio3Dev P, Workspace W, uint32_t 
             inv = f_mul(inv, f_sub(r, w));
             L[j] = f_mul(f_mul(k, w), dinv);
         }
+        if (P.circuit != CIRCUIT_AVERAGE) {
+            // what the query kernel would otherwise compute with a whole wavefront per value:
+            // small power tables of rho and r, and the weights as limbs with
+            // M_j = L_j rho^(chunk (j-1)) next to L_j
+            RepPow *pw = &W.pows[i];
+            const F128 rho = sc->jr[P.jr_len];      // run 2's joint_rand[0]
+            F128 t = rho;
+            for (int q = 0; q < 8; q++) { pw->rho_lo[q] = t; if (q < 7) t = f_mul(t, rho); }
+            F128 u = f_one();
+            for (int q = 0; q < 8; q++) { pw->rho_hi[q] = u; u = f_mul(u, t); }     // t = rho^8
+            const F128 u2 = f_sqr(u);                                               // u = rho^64
+            pw->rho64[0] = f_one(); pw->rho64[1] = u; pw->rho64[2] = u2; pw->rho64[3] = f_mul(u2, u); pw->rho64[4] = f_sqr(u2);
+            t = f_one();
+            for (int q = 0; q < 8; q++) { pw->r_lo[q] = t; t = f_mul(t, r); }
+            u = f_one();
+            for (int q = 0; q < 8; q++) { pw->r_hi[q] = u; u = f_mul(u, t); }       // t = r^8
+            pw->r64 = u;
+            const F128 rc = f_pow_u32(rho, P.chunk);
+            uint4 *wl = reinterpret_cast<uint4 *>(W.wlimbs + (uint64_t)i * 12 * P.calls);
+            F128 pj = f_one(), sumL = f_zero();
+            for (uint32_t j = 1; j <= P.calls; j++) {
+                const F128 l = L[j], m = f_mul(l, pj);
+                sumL = f_add(sumL, l);
+                uint32_t tl[5], tm[5];
+                f_split26(l, tl);
+                f_split26(m, tm);
+                wl[3 * (j - 1)] = make_uint4(tl[0], tl[1], tl[2], tl[3]);
+                wl[3 * (j - 1) + 1] = make_uint4(tl[4], tm[0], tm[1], tm[2]);
+                wl[3 * (j - 1) + 2] = make_uint4(tm[3], tm[4], 0, 0);
+                pj = f_mul(pj, rc);
+            }
+            pw->L0 = L[0];
+            pw->h_sumL = f_mul(P.half, sumL);
+        }
     } else {
         // testing id: AES128_vk(client_id.to_le_bytes()) (main.rs:51, common/src/prg.rs:650-655)
         const uint8_t *sbox = aes_rk + 176;
@@ -239,158 +283,300 @@ __global__ void __launch_bounds__(256) k_hash(Prio3Dev P, Workspace W, uint32_t 
 }
 
 // --------------------------------------------------------------------------------- query ----
-// One wavefront per report.  Type::query for the ParallelSum<Mul> circuits (flp.rs:359-479,
-// types.rs:623-639, 410-437, 742-777) in barycentric form: wire w's polynomial evaluated at r
-// is sum_j L_j(r) f[w][j], with f[2k][j] = rho^(i+1) x_i, f[2k+1][j] = x_i - h, i = (j-1) chunk + k,
-// f[w][0] = proof[w]; v[0] = <s, G> (sum of the gadget polynomial over the call points).
-// Then decide on both public proofs (flp.rs:483-512), the differences, and the RLC tag
-// (prio3.rs:2703-2871).  `lds` holds L_j and M_j = L_j rho^(chunk (j-1)) per wave.
+// One workgroup of S = blockDim.x / 64 wavefronts per report.  Type::query for the
+// ParallelSum<Mul> circuits (flp.rs:359-479, types.rs:623-639, 410-437, 742-777) in barycentric
+// form: wire w's polynomial evaluated at r is sum_j L_j(r) f[w][j], with
+// f[2k][j] = rho^(i+1) x_i, f[2k+1][j] = x_i - h, i = (j-1) chunk + k, f[w][0] = proof[w];
+// v[0] = <s, G> (sum of the gadget polynomial over the call points).  Then decide on both public
+// proofs (flp.rs:483-512), the differences, and the RLC tag (prio3.rs:2703-2871).
+//
+// The measurement share is streamed once.  Wave w owns the gadget slots k = 64 w + lane (+ 64 S,
+// ...) and carries A_k = sum_j M_j x_(j,k) and B_k = sum_j L_j x_(j,k) as lazy column sums
+// (f128.hpp), M_j = L_j rho^(chunk (j-1)); the weights (limbs, written by the hash kernel) sit in
+// LDS and are read as broadcasts.  SumVec's truncate (types.rs:641-648) needs the same elements
+// in the other direction (all bits of one output in one lane), so every wave parks the elements
+// of eight calls in LDS as they arrive and turns them into outputs from there; shapes that do
+// not tile this way are truncated from global memory at the end.  The gadget polynomial and the
+// decide checks are done by the first and last wave; partial results meet in LDS.
+
+constexpr uint32_t QT_CALLS = 8;                        // calls per truncate tile
+constexpr uint32_t QT_STAGE_U4 = QT_CALLS * 64 * 17 / 16;   // uint4 slots per wave: 16 B of padding every 16 elements
+__device__ __forceinline__ uint32_t stage_slot(uint32_t p) { return p + (p >> 4); }
+
+// sum_l 2^l x[e bits + l] for outputs e0 + lane < e1, read from global memory
+__device__ __forceinline__ void truncate_block(const Prio3Dev &P, const uint8_t *meas, F128 *out_row, uint32_t e0,
+                                               uint32_t e1, uint32_t lane) {
+    const uint32_t e = e0 + lane;
+    if (e >= e1) return;
+    const uint8_t *bits = meas + 16ull * e * P.bits;
+    if (P.bits <= 32) {
+        LazySmall acc;
+        f_small_zero(acc);
+        uint32_t l = 0;
+        for (; l + 8 <= P.bits; l += 8) {       // eight loads in flight
+            F128 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) x[u] = ld128g(bits + 16ull * (l + u));
+#pragma unroll
+            for (int u = 0; u < 8; u++) f_small_mac(acc, x[u], 1u << (l + u));
+        }
+        for (; l < P.bits; l++) f_small_mac(acc, ld128g(bits + 16ull * l), 1u << l);
+        out_row[e] = f_small_reduce(acc);
+    } else {
+        F128 acc = f_zero();
+        for (uint32_t l = P.bits; l-- > 0;) acc = f_add(f_dbl(acc), ld128g(bits + 16ull * l));
+        out_row[e] = acc;
+    }
+}
+
+struct QueryShared {      // behind the weight rows in LDS
+    F128 tag[4], sum_x[4], dec[2];
+    uint32_t bad[4];
+};
+
+template <bool HIST>
 __global__ void __launch_bounds__(256) k_query_psum(Prio3Dev P, Workspace W, uint32_t n, uint8_t *tags,
                                                     uint8_t *out_shares, int32_t *status) {
-    extern __shared__ F128 lds[];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t i = blockIdx.x * (blockDim.x >> 6) + wave;
+    extern __shared__ uint32_t lds_w[];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, S = blockDim.x >> 6;
+    const uint32_t i = blockIdx.x;
     if (i >= n) return;
     uint8_t *tag_out = tags + 16ull * i;
     F128 *out_row = reinterpret_cast<F128 *>(out_shares) + (uint64_t)i * P.output_len;
-    if (status[i] != ST_OK) {
-        for (uint32_t e = lane; e < P.output_len; e += 64) out_row[e] = f_zero();
-        if (lane == 0) st128(tag_out, f_zero());
+    if (status[i] != ST_OK) {               // uniform over the workgroup
+        for (uint32_t e = threadIdx.x; e < P.output_len; e += blockDim.x) out_row[e] = f_zero();
+        if (threadIdx.x == 0) st128(tag_out, f_zero());
         return;
     }
-    F128 *Lw = lds + (uint64_t)wave * 2 * P.n_weights, *Mw = Lw + P.n_weights;
+    const uint32_t calls = P.calls;
+    uint32_t *wl = lds_w;                   // [calls][12]: L limbs, M limbs, pad
+    QueryShared *sh = reinterpret_cast<QueryShared *>(lds_w + 12 * (uint64_t)calls);
+    uint4 *stage = reinterpret_cast<uint4 *>(sh + 1) + (uint64_t)wave * QT_STAGE_U4;
     const RepDesc d = W.desc[i];
     const RepScal *sc = &W.scal[i];
     const uint8_t *pp0 = d.tail + 40, *pp1 = pp0 + 16ull * P.verifier_len;
     const F128 *rlc = W.rlc + (uint64_t)i * (P.verifier_len + 5);
-    const F128 r = sc->qr[1];
-    const F128 rho = sc->jr[P.jr_len];          // run 2's joint_rand[0]
     const bool leader = d.role == 0;
     uint32_t bad = 0;                           // any element >= p (FieldError::ModulusOverflow)
 
-    // weights to LDS; M_j = L_j * rho^(chunk (j-1))
-    const F128 *Lg = W.weights + (uint64_t)i * P.n_weights;
-    for (uint32_t j = lane; j < P.n_weights; j += 64) {
-        F128 l = Lg[j];
-        Lw[j] = l;
-        Mw[j] = j ? f_mul(l, f_pow_u32(rho, P.chunk * (j - 1))) : f_zero();
+    // weight limbs (written by the hash kernel) to LDS
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(W.wlimbs + (uint64_t)i * 12 * calls);
+        uint4 *dst = reinterpret_cast<uint4 *>(wl);
+        for (uint32_t t = threadIdx.x; t < 3 * calls; t += blockDim.x) dst[t] = src[t];
     }
-    // each wave reads back only its own LDS rows: order the LDS writes before the reads of
-    // this wave (no workgroup barrier: other waves of the block may already have returned)
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    F128 sumL = f_zero();                       // sum_{j>=1} L_j
-    for (uint32_t j = 1 + lane; j < P.n_weights; j += 64) sumL = f_add(sumL, Lw[j]);
-    sumL = wave_sum(sumL);
-    const F128 L0 = Lw[0];
-    const F128 h_sumL = f_mul(P.half, sumL);
-
-    // Leader only: proof share of run 1 is hashed, never evaluated; it still has to decode
-    if (leader)
-        for (uint32_t e = lane; e < P.proof_len; e += 64) {
-            F128 v = ld128(d.proof1 + 16ull * e);
-            bad |= !f_in_range(v.lo, v.hi);
-        }
+    const RepPow *pw = &W.pows[i];
+    const F128 L0 = pw->L0, h_sumL = pw->h_sumL;
+    const F128 rho_lane = f_mul(pw->rho_lo[lane & 7], pw->rho_hi[lane >> 3]);      // rho^(lane + 1)
+    F128 rho_kb = pw->rho64[wave];                                                  // rho^kb
+    __syncthreads();
 
     F128 tag = f_zero();
-    F128 sum_x = f_zero();                      // Histogram's sum check
-    // wires
-    for (uint32_t k = lane; k < P.chunk; k += 64) {
-        F128 A = f_zero(), B = f_zero();
-        for (uint32_t j = 1; j < P.n_weights; j++) {
-            uint32_t idx = (j - 1) * P.chunk + k;
-            if (idx < P.input_len) {
-                F128 x = ld128(d.meas + 16ull * idx);
-                bad |= !f_in_range(x.lo, x.hi);
-                A = f_add(A, f_mul(Mw[j], x));
-                B = f_add(B, f_mul(Lw[j], x));
-                sum_x = f_add(sum_x, x);
+    LazySmall sum_x;                            // Histogram's sum check
+    f_small_zero(sum_x);
+    uint32_t susp = 0;                          // a top word of all ones: look again, exactly
+    const bool trunc = P.circuit == CIRCUIT_SUMVEC;
+    // truncate through LDS: the 64 slots of a wave hold whole outputs, 8 consecutive elements per lane
+    const bool lds_trunc = trunc && (P.bits == 8 || P.bits == 16 || P.bits == 32) && (P.chunk & 63) == 0;
+    const uint32_t lpo = P.bits >> 3;           // lanes per output in that case
+
+    for (uint32_t kb = 64 * wave; kb < P.chunk; kb += 64 * S) {
+        const uint32_t k = kb + lane;
+        Lazy cA, cB;
+        f_lazy_zero(cA);
+        f_lazy_zero(cB);
+        F128 Af = f_zero(), Bf = f_zero();
+        uint32_t since = 0;
+        // element of call jj (0-based) in this lane's slot, or element 0 (masked) outside the share
+        auto fetch = [&](uint32_t jj, bool &ok) -> F128 {
+            const uint64_t idx = (uint64_t)jj * P.chunk + k;
+            ok = jj < calls && k < P.chunk && idx < P.input_len;
+            return ld128g(d.meas + 16ull * (ok ? idx : 0));
+        };
+        F128 xb[4];
+        bool okb[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) xb[u] = fetch(u, okb[u]);
+        for (uint32_t jj = 0; jj < calls; jj += 4) {
+            // cut the four elements that have arrived into limbs, put the next four loads in
+            // flight straight away, then do the arithmetic under them
+            uint32_t xl[4][5];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                F128 v = xb[u];
+                if (!okb[u]) v = f_zero();
+                susp |= (uint32_t)(v.hi >> 32) == 0xffffffffu;
+                f_split26(v, xl[u]);
+                if (HIST) f_small_mac(sum_x, v, 1u);
+                if (lds_trunc)
+                    stage[stage_slot(((jj & 4) + u) * 64 + lane)] =
+                        make_uint4((uint32_t)v.lo, (uint32_t)(v.lo >> 32), (uint32_t)v.hi, (uint32_t)(v.hi >> 32));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) xb[u] = fetch(jj + u + 4, okb[u]);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t jc = jj + u < calls ? jj + u : calls - 1;   // a call past the end has x = 0
+                const uint4 *src = reinterpret_cast<const uint4 *>(wl + 12 * jc);
+                const uint4 w0 = src[0], w1 = src[1], w2 = src[2];
+                const uint32_t wL[5] = {w0.x, w0.y, w0.z, w0.w, w1.x};
+                const uint32_t wM[5] = {w1.y, w1.z, w1.w, w2.x, w2.y};
+                f_lazy_mac(cA, xl[u], wM);
+                f_lazy_mac(cB, xl[u], wL);
+            }
+            since += 4;
+            if (since + 4 > LAZY_MAX_TERMS) {
+                Af = f_add(Af, f_lazy_reduce(cA));
+                Bf = f_add(Bf, f_lazy_reduce(cB));
+                f_lazy_zero(cA);
+                f_lazy_zero(cB);
+                since = 0;
+            }
+            if (lds_trunc && ((jj & 4) || jj + 4 >= calls)) {
+                // a tile of eight calls is parked: lane handles positions 8 lane .. 8 lane + 7
+                // (call t = lane / 8 of the tile, slots 8 (lane % 8) ..), lpo lanes make one output
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t j0 = jj & ~7u, t = lane >> 3, kk0 = (lane & 7) * 8;
+                const uint32_t l0 = kk0 & (P.bits - 1);
+                LazySmall acc;
+                f_small_zero(acc);
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const uint4 v = stage[stage_slot(lane * 8 + q)];
+                    f_small_mac(acc, F128{v.x | ((uint64_t)v.y << 32), v.z | ((uint64_t)v.w << 32)}, 1u << (l0 + q));
+                }
+                for (uint32_t m = 1; m < lpo; m <<= 1)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) acc.c[q] += __shfl_xor((unsigned long long)acc.c[q], m, 64);
+                const uint64_t idx0 = (uint64_t)(j0 + t) * P.chunk + kb + (kk0 - l0);
+                const uint64_t e = idx0 / P.bits;
+                if ((lane & (lpo - 1)) == 0 && j0 + t < calls && e < P.output_len) out_row[e] = f_small_reduce(acc);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
             }
         }
-        F128 s_even = ld128(d.proof2 + 16ull * (2 * k)), s_odd = ld128(d.proof2 + 16ull * (2 * k + 1));
-        bad |= !f_in_range(s_even.lo, s_even.hi) | !f_in_range(s_odd.lo, s_odd.hi);
-        F128 v_even = f_add(f_mul(L0, s_even), f_mul(f_pow_u32(rho, k + 1), A));
-        F128 v_odd = f_sub(f_add(f_mul(L0, s_odd), B), h_sumL);
-        F128 q_even = ld128(pp1 + 16ull * (1 + 2 * k)), q_odd = ld128(pp1 + 16ull * (2 + 2 * k));
-        bad |= !f_in_range(q_even.lo, q_even.hi) | !f_in_range(q_odd.lo, q_odd.hi);
-        if (leader) { v_even = f_sub(v_even, q_even); v_odd = f_sub(v_odd, q_odd); }
-        tag = f_add(tag, f_add(f_mul(rlc[1 + 2 * k], v_even), f_mul(rlc[2 + 2 * k], v_odd)));
+        // this lane's slot: seeds (call 0), differences against the public proof, RLC
+        if (k < P.chunk) {
+            const F128 A = f_add(Af, f_lazy_reduce(cA));
+            const F128 B = f_add(Bf, f_lazy_reduce(cB));
+            const F128 rk = f_mul(rho_lane, rho_kb);                                    // rho^(k + 1)
+            F128 s_even = ld128g(d.proof2 + 16ull * (2 * k)), s_odd = ld128g(d.proof2 + 16ull * (2 * k + 1));
+            bad |= !f_in_range(s_even.lo, s_even.hi) | !f_in_range(s_odd.lo, s_odd.hi);
+            F128 v_even = f_add(f_mul(L0, s_even), f_mul(rk, A));
+            F128 v_odd = f_sub(f_add(f_mul(L0, s_odd), B), h_sumL);
+            F128 q_even = ld128g(pp1 + 16ull * (1 + 2 * k)), q_odd = ld128g(pp1 + 16ull * (2 + 2 * k));
+            bad |= !f_in_range(q_even.lo, q_even.hi) | !f_in_range(q_odd.lo, q_odd.hi);
+            if (leader) { v_even = f_sub(v_even, q_even); v_odd = f_sub(v_odd, q_odd); }
+            tag = f_add(tag, f_add(f_mul(rlc[1 + 2 * k], v_even), f_mul(rlc[2 + 2 * k], v_odd)));
+        }
+        if (kb + 64 * S < P.chunk) rho_kb = f_mul(rho_kb, pw->rho64[S]);
     }
-    // gadget polynomial G = proof2[arity ..]: G(r) and <s, G>
-    const uint8_t *G = d.proof2 + 16ull * P.arity;
+    // the exact range check of the share, in the rare case that a top word was all ones
+    if (wave_or(susp))
+        for (uint32_t e = lane; e < P.input_len; e += 64) {
+            F128 x = ld128g(d.meas + 16ull * e);
+            bad |= !f_in_range(x.lo, x.hi);
+        }
+    // truncate (types.rs:641-648 / 439-442) -> out share, where it was not done on the way
+    if (trunc && !lds_trunc) {
+        for (uint32_t e0 = 64 * wave; e0 < P.output_len; e0 += 64 * S)
+            truncate_block(P, d.meas, out_row, e0, e0 + 64 < P.output_len ? e0 + 64 : P.output_len, lane);
+    } else if (!trunc) {
+        for (uint32_t e = threadIdx.x; e < P.output_len; e += blockDim.x) out_row[e] = ld128g(d.meas + 16ull * e);
+    }
+
+    // first wave: gadget polynomial G = proof2[arity ..]: G(r) and <s, G>
     F128 g_at_r = f_zero(), v0 = f_zero();
-    {
-        F128 rpow = f_pow_u32(r, lane), r64 = f_sqr_n(r, 6);
+    if (wave == 0) {
+        const uint8_t *G = d.proof2 + 16ull * P.arity;
+        Lazy cg, cv;
+        f_lazy_zero(cg);
+        f_lazy_zero(cv);
+        F128 rpow = f_mul(pw->r_lo[lane & 7], pw->r_hi[lane >> 3]), r64 = pw->r64;
+        uint32_t since = 0;
         for (uint32_t e = lane; e < P.gpoly_len; e += 64) {
-            F128 c = ld128(G + 16ull * e);
+            F128 c = ld128g(G + 16ull * e);
             bad |= !f_in_range(c.lo, c.hi);
-            g_at_r = f_add(g_at_r, f_mul(c, rpow));
-            v0 = f_add(v0, f_mul(c, P.s_tab[e]));
+            uint32_t cl[5], t1[5], t2[5];
+            f_split26(c, cl);
+            f_split26(rpow, t1);
+            f_split26(P.s_tab[e], t2);
+            f_lazy_mac(cg, cl, t1);
+            f_lazy_mac(cv, cl, t2);
             rpow = f_mul(rpow, r64);
+            if (++since == LAZY_MAX_TERMS) {
+                g_at_r = f_add(g_at_r, f_lazy_reduce(cg));
+                v0 = f_add(v0, f_lazy_reduce(cv));
+                f_lazy_zero(cg);
+                f_lazy_zero(cv);
+                since = 0;
+            }
         }
+        g_at_r = wave_sum(f_add(g_at_r, f_lazy_reduce(cg)));
+        v0 = wave_sum(f_add(v0, f_lazy_reduce(cv)));
     }
-    g_at_r = wave_sum(g_at_r);
-    v0 = wave_sum(v0);
-    if (P.circuit == CIRCUIT_HISTOGRAM) {
-        // types.rs:428-436: rho' * range_check + rho'^2 * (sum x - h)
-        F128 rho2 = sc->jr[P.jr_len + 1];
-        F128 sum_check = f_sub(wave_sum(sum_x), P.half);
-        v0 = f_add(f_mul(rho2, v0), f_mul(f_sqr(rho2), sum_check));
-    }
-
-    // decide on the two public proofs (prio3.rs:2762-2786): pp[0] == 0 and
-    // sum_k pp[1+2k] pp[2+2k] == pp[1+arity]
-    F128 dec[2];
+    // last wave: decide on the two public proofs (prio3.rs:2762-2786): pp[0] == 0 and
+    // sum_k pp[1+2k] pp[2+2k] == pp[1+arity]; Leader only: the proof share of run 1 is hashed,
+    // never evaluated, but it still has to decode
+    if (wave == S - 1) {
+        if (leader)
+            for (uint32_t e = lane; e < P.proof_len; e += 64) {
+                F128 v = ld128g(d.proof1 + 16ull * e);
+                bad |= !f_in_range(v.lo, v.hi);
+            }
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const uint8_t *pp = t ? pp1 : pp0;
-        F128 acc = f_zero();
-        for (uint32_t k = lane; k < P.chunk; k += 64) {
-            F128 a = ld128(pp + 16ull * (1 + 2 * k)), b = ld128(pp + 16ull * (2 + 2 * k));
-            bad |= !f_in_range(a.lo, a.hi) | !f_in_range(b.lo, b.hi);
-            acc = f_add(acc, f_mul(a, b));
-        }
-        acc = wave_sum(acc);
-        F128 first = ld128(pp), last = ld128(pp + 16ull * (1 + P.arity));
-        bad |= !f_in_range(first.lo, first.hi) | !f_in_range(last.lo, last.hi);
-        bool ok = f_is_zero(first) && f_eq(acc, last);
-        dec[t] = ok ? f_zero() : f_one();
-    }
-
-    // truncate (types.rs:641-648 / 439-442) -> out share
-    if (P.circuit == CIRCUIT_SUMVEC) {
-        for (uint32_t e = lane; e < P.output_len; e += 64) {
-            const uint8_t *bits = d.meas + 16ull * e * P.bits;
+        for (int t = 0; t < 2; t++) {
+            const uint8_t *pp = t ? pp1 : pp0;
             F128 acc = f_zero();
-            for (uint32_t l = P.bits; l-- > 0;) acc = f_add(f_dbl(acc), ld128(bits + 16ull * l));
-            out_row[e] = acc;
+            for (uint32_t kk = lane; kk < P.chunk; kk += 64) {
+                F128 a = ld128g(pp + 16ull * (1 + 2 * kk)), b = ld128g(pp + 16ull * (2 + 2 * kk));
+                bad |= !f_in_range(a.lo, a.hi) | !f_in_range(b.lo, b.hi);
+                acc = f_add(acc, f_mul(a, b));
+            }
+            acc = wave_sum(acc);
+            F128 first = ld128g(pp), last = ld128g(pp + 16ull * (1 + P.arity));
+            bad |= !f_in_range(first.lo, first.hi) | !f_in_range(last.lo, last.hi);
+            bool ok = f_is_zero(first) && f_eq(acc, last);
+            if (lane == 0) sh->dec[t] = ok ? f_zero() : f_one();
         }
-    } else {
-        for (uint32_t e = lane; e < P.output_len; e += 64) out_row[e] = ld128(d.meas + 16ull * e);
     }
-
+    tag = wave_sum(tag);
+    bad = wave_or(bad);
+    F128 sx = f_zero();
+    if (HIST) sx = wave_sum(f_small_reduce(sum_x));
     if (lane == 0) {
+        sh->tag[wave] = tag;
+        sh->sum_x[wave] = sx;
+        sh->bad[wave] = bad;
+    }
+    __syncthreads();
+    bad = 0;
+    for (uint32_t w = 0; w < S; w++) bad |= sh->bad[w];
+    if (bad)
+        for (uint32_t e = threadIdx.x; e < P.output_len; e += blockDim.x) out_row[e] = f_zero();
+    if (threadIdx.x == 0) {
         const uint32_t vl = P.verifier_len;
-        F128 q0 = ld128(pp1), qg = ld128(pp1 + 16ull * (1 + P.arity));
+        tag = f_zero();
+        sx = f_zero();
+        for (uint32_t w = 0; w < S; w++) { tag = f_add(tag, sh->tag[w]); sx = f_add(sx, sh->sum_x[w]); }
+        if (HIST) {
+            // types.rs:428-436: rho' * range_check + rho'^2 * (sum x - h)
+            F128 rho2 = sc->jr[P.jr_len + 1];
+            v0 = f_add(f_mul(rho2, v0), f_mul(f_sqr(rho2), f_sub(sx, P.half)));
+        }
+        F128 q0 = ld128g(pp1), qg = ld128g(pp1 + 16ull * (1 + P.arity));
         F128 d0 = leader ? f_sub(v0, q0) : v0;
         F128 dg = leader ? f_sub(g_at_r, qg) : g_at_r;
         tag = f_add(tag, f_mul(rlc[0], d0));
         tag = f_add(tag, f_mul(rlc[1 + P.arity], dg));
-        tag = f_add(tag, f_mul(rlc[vl], dec[0]));
-        tag = f_add(tag, f_mul(rlc[vl + 1], dec[1]));
+        tag = f_add(tag, f_mul(rlc[vl], sh->dec[0]));
+        tag = f_add(tag, f_mul(rlc[vl + 1], sh->dec[1]));
         if (sc->rand_diff[0]) tag = f_add(tag, rlc[vl + 2]);
         if (sc->rand_diff[1]) tag = f_add(tag, rlc[vl + 3]);
         F128 hs = leader ? f_neg(sc->hash) : sc->hash;       // prio3.rs:2844-2855
         tag = f_add(tag, f_mul(rlc[vl + 4], hs));
-    }
-    tag = wave_sum(tag);
-    bad = wave_or(bad);
-    if (bad) {
-        for (uint32_t e = lane; e < P.output_len; e += 64) out_row[e] = f_zero();
-        tag = f_zero();
-    }
-    if (lane == 0) {
-        if (bad) status[i] = ST_ERR_MODULUS;
+        if (bad) { status[i] = ST_ERR_MODULUS; tag = f_zero(); }
         // prepare_encoded_key: the Helper-role tag is negated (main.rs:53-59)
         st128(tag_out, leader ? tag : f_neg(tag));
     }
@@ -584,7 +770,25 @@ __global__ void k_test_f128(const F128 *a, const F128 *b, F128 *out, uint32_t n,
     case 0: r = f_add(a[i], b[i]); break;
     case 1: r = f_sub(a[i], b[i]); break;
     case 2: r = f_mul(a[i], b[i]); break;
-    default: r = f_inv(a[i]); break;
+    case 3: r = f_inv(a[i]); break;
+    case 4:
+    case 5: {   // the lazy dot product: one term, and LAZY_MAX_TERMS equal terms
+        uint32_t x[5], y[5];
+        f_split26(a[i], x);
+        f_split26(b[i], y);
+        Lazy acc;
+        f_lazy_zero(acc);
+        for (uint32_t t = 0; t < (op == 4 ? 1u : LAZY_MAX_TERMS); t++) f_lazy_mac(acc, x, y);
+        r = f_lazy_reduce(acc);
+        break;
+    }
+    default: {  // 6: sum_l 2^l a over l < 32 through the small-multiplier columns
+        LazySmall acc;
+        f_small_zero(acc);
+        for (uint32_t l = 0; l < 32; l++) f_small_mac(acc, a[i], 1u << l);
+        r = f_small_reduce(acc);
+        break;
+    }
     }
     out[i] = r;
 }

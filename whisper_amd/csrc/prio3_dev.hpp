@@ -56,10 +56,25 @@ struct RepScal {
     uint32_t pad[2];
 };
 
+// Per-report powers and sums for the ParallelSum query kernel, computed once per report by the
+// lane that derives the randomness (a wave-uniform value costs a whole wavefront there).
+struct RepPow {
+    F128 L0, h_sumL;    // L_0(r); h * sum_{j>=1} L_j(r)
+    F128 rho_lo[8];     // rho^(t+1), t = 0..7
+    F128 rho_hi[8];     // rho^(8t)
+    F128 rho64[5];      // rho^(64t), t = 0..4
+    F128 r_lo[8];       // r^t
+    F128 r_hi[8];       // r^(8t)
+    F128 r64;           // r^64
+};
+
 struct Workspace {
     RepDesc *desc;       // [cap]
     RepScal *scal;       // [cap]
     F128 *weights;       // [cap][n_weights]   barycentric L_j(r) for run 2
+    uint32_t *wlimbs;    // [cap][calls][12]   ParallelSum circuits: 26-bit limbs of L_j and of
+                         //                    M_j = L_j rho^(chunk (j-1)), j = 1..calls (5 + 5 + 2 pad)
+    RepPow *pows;        // [cap]
     F128 *rlc;           // [cap][verifier_len + 5]
     uint8_t *hrows;      // [cap][(input_len + 2 proof_len) * 16] expanded Helper shares
     uint32_t *hlist;     // [cap] report index of each Helper slot
