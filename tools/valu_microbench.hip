@@ -27,6 +27,8 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t seed) {
             if (OP == 11) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
             if (OP == 12) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(a[i]) : "v"(b));
             if (OP == 13) asm volatile("v_xad_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+            if (OP == 14) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0xd2" : "+v"(a[i]) : "v"(b), "v"(c));
+            if (OP == 15) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
         }
     }
     uint32_t r = 0;
@@ -76,7 +78,7 @@ int main() {
 #define R64(OP, NAME) run(NAME, [&] { hipLaunchKernelGGL(k64<OP>, dim3(blocks), dim3(256), 0, 0, (uint64_t *)out, 12345u); }, blocks)
         R(10, "v_fma_f32"); R(0, "v_xor_b32"); R(1, "v_alignbit_b32"); R(2, "v_bfi_b32"); R(5, "v_add_u32"); R(6, "v_add_co_u32");
         R(7, "v_addc_co_u32"); R(3, "v_mul_lo_u32"); R(4, "v_mul_hi_u32"); R64(8, "v_mad_u64_u32"); R64(9, "v_lshlrev_b64");
-        R(11, "v_and_or_b32"); R(12, "v_lshl_or_b32"); R(13, "v_xad_u32");
+        R(11, "v_and_or_b32"); R(12, "v_lshl_or_b32"); R(13, "v_xad_u32"); R(14, "v_bitop3_b32"); R(15, "v_perm_b32");
     }
     return 0;
 }

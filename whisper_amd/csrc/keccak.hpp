@@ -89,10 +89,59 @@ WH_HD uint64_t rotl64(uint64_t x, int n) {
         a[20] = b20 ^ (~b21 & b22); a[21] = b21 ^ (~b22 & b23); a[22] = b22 ^ (~b23 & b24); a[23] = b23 ^ (~b24 & b20); a[24] = b24 ^ (~b20 & b21); \
     } while (0)
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// gfx950 has a full-rate three-input bitwise instruction (v_bitop3_b32, truth table in the
+// immediate: a = 0xf0, b = 0xcc, c = 0xaa).  Theta's five-way parities and its application
+// become xor3 (0x96), chi becomes a ^ (~b & c) (0xd2): 122 full-rate + 58 half-rate (v_alignbit)
+// instructions a round instead of 152 + 108.
+__device__ __forceinline__ uint64_t xor3_64(uint64_t a, uint64_t b, uint64_t c) {
+    const uint32_t lo = __builtin_amdgcn_bitop3_b32((uint32_t)a, (uint32_t)b, (uint32_t)c, 0x96);
+    const uint32_t hi = __builtin_amdgcn_bitop3_b32((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32), 0x96);
+    return lo | ((uint64_t)hi << 32);
+}
+__device__ __forceinline__ uint64_t chi_64(uint64_t a, uint64_t b, uint64_t c) {
+    const uint32_t lo = __builtin_amdgcn_bitop3_b32((uint32_t)a, (uint32_t)b, (uint32_t)c, 0xd2);
+    const uint32_t hi = __builtin_amdgcn_bitop3_b32((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32), 0xd2);
+    return lo | ((uint64_t)hi << 32);
+}
+#define WH_KECCAK_ROUND_DEV(a, rc)                                                               \
+    do {                                                                                         \
+        const uint64_t c0 = xor3_64(xor3_64(a[0], a[5], a[10]), a[15], a[20]);                   \
+        const uint64_t c1 = xor3_64(xor3_64(a[1], a[6], a[11]), a[16], a[21]);                   \
+        const uint64_t c2 = xor3_64(xor3_64(a[2], a[7], a[12]), a[17], a[22]);                   \
+        const uint64_t c3 = xor3_64(xor3_64(a[3], a[8], a[13]), a[18], a[23]);                   \
+        const uint64_t c4 = xor3_64(xor3_64(a[4], a[9], a[14]), a[19], a[24]);                   \
+        const uint64_t r0 = rotl64(c0, 1), r1 = rotl64(c1, 1), r2 = rotl64(c2, 1);               \
+        const uint64_t r3 = rotl64(c3, 1), r4 = rotl64(c4, 1);                                   \
+        /* a ^ d_x with d_x = c_(x-1) ^ rot(c_(x+1), 1), in one xor3 */                          \
+        const uint64_t b0 = xor3_64(a[0], c4, r1);                                               \
+        const uint64_t b1 = rotl64(xor3_64(a[6], c0, r2), 44), b2 = rotl64(xor3_64(a[12], c1, r3), 43);   \
+        const uint64_t b3 = rotl64(xor3_64(a[18], c2, r4), 21), b4 = rotl64(xor3_64(a[24], c3, r0), 14);  \
+        const uint64_t b5 = rotl64(xor3_64(a[3], c2, r4), 28), b6 = rotl64(xor3_64(a[9], c3, r0), 20);    \
+        const uint64_t b7 = rotl64(xor3_64(a[10], c4, r1), 3), b8 = rotl64(xor3_64(a[16], c0, r2), 45);   \
+        const uint64_t b9 = rotl64(xor3_64(a[22], c1, r3), 61);                                  \
+        const uint64_t b10 = rotl64(xor3_64(a[1], c0, r2), 1), b11 = rotl64(xor3_64(a[7], c1, r3), 6);    \
+        const uint64_t b12 = rotl64(xor3_64(a[13], c2, r4), 25), b13 = rotl64(xor3_64(a[19], c3, r0), 8); \
+        const uint64_t b14 = rotl64(xor3_64(a[20], c4, r1), 18);                                 \
+        const uint64_t b15 = rotl64(xor3_64(a[4], c3, r0), 27), b16 = rotl64(xor3_64(a[5], c4, r1), 36);  \
+        const uint64_t b17 = rotl64(xor3_64(a[11], c0, r2), 10), b18 = rotl64(xor3_64(a[17], c1, r3), 15); \
+        const uint64_t b19 = rotl64(xor3_64(a[23], c2, r4), 56);                                 \
+        const uint64_t b20 = rotl64(xor3_64(a[2], c1, r3), 62), b21 = rotl64(xor3_64(a[8], c2, r4), 55);  \
+        const uint64_t b22 = rotl64(xor3_64(a[14], c3, r0), 39), b23 = rotl64(xor3_64(a[15], c4, r1), 41); \
+        const uint64_t b24 = rotl64(xor3_64(a[21], c0, r2), 2);                                  \
+        a[0] = chi_64(b0, b1, b2) ^ (rc);                                                        \
+        a[1] = chi_64(b1, b2, b3); a[2] = chi_64(b2, b3, b4); a[3] = chi_64(b3, b4, b0); a[4] = chi_64(b4, b0, b1);      \
+        a[5] = chi_64(b5, b6, b7); a[6] = chi_64(b6, b7, b8); a[7] = chi_64(b7, b8, b9); a[8] = chi_64(b8, b9, b5); a[9] = chi_64(b9, b5, b6); \
+        a[10] = chi_64(b10, b11, b12); a[11] = chi_64(b11, b12, b13); a[12] = chi_64(b12, b13, b14); a[13] = chi_64(b13, b14, b10); a[14] = chi_64(b14, b10, b11); \
+        a[15] = chi_64(b15, b16, b17); a[16] = chi_64(b16, b17, b18); a[17] = chi_64(b17, b18, b19); a[18] = chi_64(b18, b19, b15); a[19] = chi_64(b19, b15, b16); \
+        a[20] = chi_64(b20, b21, b22); a[21] = chi_64(b21, b22, b23); a[22] = chi_64(b22, b23, b24); a[23] = chi_64(b23, b24, b20); a[24] = chi_64(b24, b20, b21); \
+    } while (0)
+#endif
+
 WH_HD void keccak_f1600(uint64_t (&a)[25]) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
-    for (int r = 0; r < 24; r++) WH_KECCAK_ROUND(a, KECCAK_RC_DEV[r]);
+    for (int r = 0; r < 24; r++) WH_KECCAK_ROUND_DEV(a, KECCAK_RC_DEV[r]);
 #else
     for (int r = 0; r < 24; r++) WH_KECCAK_ROUND(a, KECCAK_RC_HOST[r]);
 #endif
