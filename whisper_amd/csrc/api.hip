@@ -64,12 +64,12 @@ hipEvent_t ev_get(wh_ctx *c) {
 }
 // brackets one kernel launch with events when profiling is on
 struct KTimer {
-    wh_ctx *c; hipEvent_t a = nullptr, b = nullptr; int id;
-    KTimer(wh_ctx *c_, int id_) : c(c_), id(id_) {
-        if (c->profiling) { a = ev_get(c); b = ev_get(c); if (a) (void)hipEventRecord(a, c->stream); }
+    wh_ctx *c; hipEvent_t a = nullptr, b = nullptr; int id; hipStream_t st;
+    KTimer(wh_ctx *c_, int id_, hipStream_t st_ = nullptr) : c(c_), id(id_), st(st_ ? st_ : c_->stream) {
+        if (c->profiling) { a = ev_get(c); b = ev_get(c); if (a) (void)hipEventRecord(a, st); }
     }
     ~KTimer() {
-        if (c->profiling && a && b) { (void)hipEventRecord(b, c->stream); c->evs.push_back({a, b, id}); }
+        if (c->profiling && a && b) { (void)hipEventRecord(b, st); c->evs.push_back({a, b, id}); }
     }
 };
 
@@ -111,7 +111,7 @@ void aes_tables(const uint8_t key[16], uint8_t out[432]) {
 int32_t alloc_workspace(wh_ctx *c, uint64_t cap) {
     if (cap <= c->cap) return WH_OK;
     Workspace &W = c->W;
-    void *ptrs[] = {W.desc, W.scal, W.weights, W.wlimbs, W.pows, W.rlc, W.hrows, W.hlist, W.counters};
+    void *ptrs[] = {W.desc, W.scal, W.weights, W.wlimbs, W.pows, W.rlc, W.hrows, W.hlist, W.llist, W.counters};
     for (void *p : ptrs) if (p) HIPCHK(c, hipFree(p));
     W = Workspace{};
     c->cap = 0;
@@ -127,6 +127,7 @@ int32_t alloc_workspace(wh_ctx *c, uint64_t cap) {
     }
     HIPCHK(c, hipMalloc((void **)&W.hrows, cap * W.hrow_bytes));
     HIPCHK(c, hipMalloc((void **)&W.hlist, cap * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void **)&W.llist, cap * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc((void **)&W.counters, 64));
     c->cap = cap;
     return WH_OK;
@@ -210,7 +211,7 @@ void wh_ctx_destroy(wh_ctx *c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_omega, c->d_stab, c->d_aes, c->d_out_shares, c->d_status_own, c->d_keep_eff, c->d_partials,
                     c->d_blob, c->d_offsets, c->d_tags, c->d_ids, c->W.desc, c->W.scal, c->W.weights, c->W.wlimbs, c->W.pows, c->W.rlc,
-                    c->W.hrows, c->W.hlist, c->W.counters};
+                    c->W.hrows, c->W.hlist, c->W.llist, c->W.counters};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
@@ -257,25 +258,26 @@ int32_t wh_prio3_prepare_batch_dev(wh_ctx *c, const uint8_t verify_key[16], cons
     const size_t lds = polyeval ? 4 * (size_t)z.m * sizeof(F128)
                                 : 48 * (size_t)z.calls + sizeof(QueryShared) + qwaves * (size_t)QT_STAGE_U4 * 16;
     if (lds > 64 * 1024) { c->err = "circuit has too many gadget calls for the query kernel's LDS rows"; return WH_ERR_UNSUPPORTED; }
-    typedef void (*query_fn)(Prio3Dev, Workspace, uint32_t, uint8_t *, uint8_t *, int32_t *);
+    typedef void (*query_fn)(Prio3Dev, Workspace, uint8_t *, uint8_t *, int32_t *);
     const query_fn qfn = polyeval ? k_query_polyeval
                                   : (c->params.circuit == WH_HISTOGRAM ? k_query_psum<true> : k_query_psum<false>);
+    uint8_t *d_out = reinterpret_cast<uint8_t *>(c->d_out_shares);
     for (uint64_t base = 0; base < n; base += c->cap) {
         const uint32_t nb = (uint32_t)((n - base < c->cap) ? n - base : c->cap);
         const uint32_t npad = (nb + 255) / 256 * 256;
+        uint8_t *tags_b = d_tags + 16 * base, *out_b = d_out + 16 * base * z.output_len;
         HIPCHK(c, hipMemsetAsync(c->W.counters, 0, 64, c->stream));
         { KTimer t_(c, WH_K_PARSE);
         hipLaunchKernelGGL(k_parse, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, d_blob, d_offsets + base, nb,
-                           d_status + base); }
+                           d_status + base, tags_b, out_b); }
         { KTimer t_(c, WH_K_EXPAND);
         launch_expand(c->P, c->W, npad, c->stream); }
         { KTimer t_(c, WH_K_HASH);
-        hipLaunchKernelGGL(k_hash, dim3(2 * npad / 256), dim3(256), 0, c->stream, c->P, c->W, nb, npad, vk0, vk1,
+        hipLaunchKernelGGL(k_hash, dim3(2 * npad / 256), dim3(256), 0, c->stream, c->P, c->W, npad, vk0, vk1,
                            c->d_aes, d_ids + 16 * base, d_status + base); }
         { KTimer t_(c, WH_K_QUERY);
-        hipLaunchKernelGGL(qfn, dim3(polyeval ? (nb + 3) / 4 : nb), dim3(64 * qwaves), lds, c->stream, c->P, c->W, nb,
-                           d_tags + 16 * base, reinterpret_cast<uint8_t *>(c->d_out_shares + base * z.output_len),
-                           d_status + base); }
+        hipLaunchKernelGGL(qfn, dim3(polyeval ? (nb + 3) / 4 : nb), dim3(64 * qwaves), lds, c->stream, c->P, c->W,
+                           tags_b, out_b, d_status + base); }
         HIPCHK(c, hipGetLastError());
     }
     return WH_OK;

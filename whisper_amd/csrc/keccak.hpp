@@ -233,7 +233,23 @@ struct Sponge {
     WH_HD void absorb3(const uint8_t *p, uint32_t len, const uint8_t *p2, uint32_t len2, const uint8_t *p3,
                        uint32_t len3) {
         for (;;) {
-            if (pos == SHAKE128_RATE) { keccak_f1600(st); pos = 0; }
+            if (pos == SHAKE128_RATE) {
+                // a whole block follows: put its loads in flight under the permutation
+                const bool pre = len >= SHAKE128_RATE;
+                uint64_t w[RATE_WORDS];
+                if (pre) {
+#pragma unroll
+                    for (int i = 0; i < (int)RATE_WORDS; i++) w[i] = ld64(p + 8 * i);
+                }
+                keccak_f1600(st);
+                pos = 0;
+                if (pre) {
+#pragma unroll
+                    for (int i = 0; i < (int)RATE_WORDS; i++) st[i] ^= w[i];
+                    p += SHAKE128_RATE; len -= SHAKE128_RATE; pos = SHAKE128_RATE;
+                    continue;
+                }
+            }
             if (!len) {
                 if (!len2 && !len3) break;
                 p = p2; len = len2; p2 = p3; len2 = len3; len3 = 0;

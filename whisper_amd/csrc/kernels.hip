@@ -4,7 +4,7 @@
 // hhcore/src/bucket.rs:48-55).
 //
 // Pipeline over one sub-batch of encoded reports resident in HBM:
-//   parse   (lane / report)   header checks, pointers, Helper compaction
+//   parse   (lane / report)   header checks, pointers, per-role report lists
 //   expand  (lane / Helper)   SHAKE128 expansion of the Helper's seeds into share rows
 //   hash    (lane / report)   joint-rand + query-rand Fiat-Shamir sponges, barycentric weights;
 //                             public-parts hash, RLC stream, AES testing id
@@ -62,12 +62,21 @@ __device__ __forceinline__ F128 f_pow_u32(F128 x, uint32_t e) {
     return r;
 }
 
+// Report handled by slot `slot` of a per-report kernel: the well-formed Leader-role reports
+// first, then the Helper-role ones, so that a wavefront (almost always) holds one role only.
+__device__ __forceinline__ bool report_of_slot(const Workspace &W, uint32_t slot, uint32_t &i) {
+    const uint32_t nl = W.counters[1], nh = W.counters[0];
+    if (slot >= nl + nh) return false;
+    i = slot < nl ? W.llist[slot] : W.hlist[slot - nl];
+    return true;
+}
+
 // --------------------------------------------------------------------------------- parse ----
 // VdafBatchedKey::decode_with_param (vdaf.rs:164-192) as far as structure goes: lengths,
 // agg_id, num_queries.  Field-element range checks happen where the elements are loaded
 // (query kernel).  Trailing bytes are not looked at (server-batch-prio3/src/main.rs:46-47).
 __global__ void k_parse(Prio3Dev P, Workspace W, const uint8_t *blob, const uint64_t *offsets, uint32_t n,
-                        int32_t *status) {
+                        int32_t *status, uint8_t *tags, uint8_t *out_shares) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint8_t *rep = blob + offsets[i];
@@ -111,6 +120,14 @@ __global__ void k_parse(Prio3Dev P, Workspace W, const uint8_t *blob, const uint
             d.jr_blind = rep + 49 + 32;
         }
     }
+    // the later kernels run per role over the two lists; a malformed report is in neither and
+    // gets its (zero) outputs here
+    if (!st && d.role == 0) W.llist[atomicAdd(&W.counters[1], 1u)] = i;
+    if (st) {
+        F128 *out_row = reinterpret_cast<F128 *>(out_shares) + (uint64_t)i * P.output_len;
+        for (uint32_t e = 0; e < P.output_len; e++) out_row[e] = f_zero();
+        st128(tags + 16ull * i, f_zero());
+    }
     W.desc[i] = d;
     status[i] = st;
 }
@@ -126,13 +143,14 @@ __global__ void k_parse(Prio3Dev P, Workspace W, const uint8_t *blob, const uint
 // Job B (lanes [npad, 2 npad)): hash of the public parts (:2808-2840), RLC coefficients
 //   (:2859-2862), testing id (main.rs:51).
 // All sponges of a lane go through one loop body; a wave-uniform switch picks the inputs.
-__global__ void __launch_bounds__(256) k_hash(Prio3Dev P, Workspace W, uint32_t n, uint32_t npad, uint64_t vk0,
+__global__ void __launch_bounds__(256) k_hash(Prio3Dev P, Workspace W, uint32_t npad, uint64_t vk0,
                                               uint64_t vk1, const uint8_t *aes_rk, uint8_t *testing_ids,
                                               int32_t *status) {
     uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t which = job >= npad;
-    uint32_t i = which ? job - npad : job;
-    if (i >= n || status[i] != ST_OK) return;
+    uint32_t slot = which ? job - npad : job;
+    uint32_t i;
+    if (!report_of_slot(W, slot, i) || status[i] != ST_OK) return;
     const RepDesc d = W.desc[i];
     RepScal *sc = &W.scal[i];
     const uint8_t *ps_parts = d.base + 16;
@@ -335,12 +353,12 @@ struct QueryShared {      // behind the weight rows in LDS
 };
 
 template <bool HIST>
-__global__ void __launch_bounds__(256) k_query_psum(Prio3Dev P, Workspace W, uint32_t n, uint8_t *tags,
+__global__ void __launch_bounds__(256) k_query_psum(Prio3Dev P, Workspace W, uint8_t *tags,
                                                     uint8_t *out_shares, int32_t *status) {
     extern __shared__ uint32_t lds_w[];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, S = blockDim.x >> 6;
-    const uint32_t i = blockIdx.x;
-    if (i >= n) return;
+    uint32_t i;
+    if (!report_of_slot(W, blockIdx.x, i)) return;
     uint8_t *tag_out = tags + 16ull * i;
     F128 *out_row = reinterpret_cast<F128 *>(out_shares) + (uint64_t)i * P.output_len;
     if (status[i] != ST_OK) {               // uniform over the workgroup
@@ -590,12 +608,13 @@ __global__ void __launch_bounds__(256) k_query_psum(Prio3Dev P, Workspace W, uin
 //   v[1] = L_0 proof[0] + sum_j L_j x_{j-1}    -- the single wire polynomial at r
 //   v[2] = G(r)
 // decide on a public proof: pp[0] == 0 and pp[1]^2 - pp[1] == pp[2].
-__global__ void __launch_bounds__(256) k_query_polyeval(Prio3Dev P, Workspace W, uint32_t n, uint8_t *tags,
+__global__ void __launch_bounds__(256) k_query_polyeval(Prio3Dev P, Workspace W, uint8_t *tags,
                                                         uint8_t *out_shares, int32_t *status) {
     extern __shared__ F128 lds[];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t i = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (i >= n) return;
+    const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + wave;
+    uint32_t i;
+    if (!report_of_slot(W, slot, i)) return;
     uint8_t *tag_out = tags + 16ull * i;
     F128 *out_row = reinterpret_cast<F128 *>(out_shares) + (uint64_t)i;   // output_len == 1
     if (status[i] != ST_OK) {

@@ -78,7 +78,8 @@ struct Workspace {
     F128 *rlc;           // [cap][verifier_len + 5]
     uint8_t *hrows;      // [cap][(input_len + 2 proof_len) * 16] expanded Helper shares
     uint32_t *hlist;     // [cap] report index of each Helper slot
-    uint32_t *counters;  // [0] = number of Helpers
+    uint32_t *llist;     // [cap] report indices of the Leader-role reports
+    uint32_t *counters;  // [0] = number of Helpers, [1] = number of Leaders (well-formed reports only)
     uint64_t hrow_bytes;
 };
 
