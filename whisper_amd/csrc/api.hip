@@ -336,7 +336,7 @@ static int32_t sum_rows(wh_ctx *c, const F128 *rows, const uint8_t *d_keep, uint
     if ((rc = ensure(c, c->d_partials, c->partials_cap, (uint64_t)nblocks * rstep * len))) return rc;
     { KTimer t_(c, WH_K_AGG);
     hipLaunchKernelGGL(k_agg_partial, dim3(nblocks), dim3(256), 0, c->stream, rows, d_keep, n, len, (uint32_t)rpb, c->d_partials);
-    hipLaunchKernelGGL(k_agg_final, dim3((len + 255) / 256), dim3(256), 0, c->stream, c->d_partials, nblocks * rstep, len, d_out); }
+    hipLaunchKernelGGL(k_agg_final, dim3((len + 15) / 16), dim3(256), 0, c->stream, c->d_partials, nblocks * rstep, len, d_out); }
     HIPCHK(c, hipGetLastError());
     return WH_OK;
 }

@@ -353,7 +353,7 @@ struct QueryShared {      // behind the weight rows in LDS
 };
 
 template <bool HIST>
-__global__ void __launch_bounds__(256) k_query_psum(Prio3Dev P, Workspace W, uint8_t *tags,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_query_psum(Prio3Dev P, Workspace W, uint8_t *tags,
                                                     uint8_t *out_shares, int32_t *status) {
     extern __shared__ uint32_t lds_w[];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, S = blockDim.x >> 6;
@@ -746,12 +746,25 @@ __global__ void __launch_bounds__(256) k_agg_partial(const F128 *rows, const uin
         partials[((uint64_t)blockIdx.x * rstep + sub) * len + e] = acc;
     }
 }
-__global__ void k_agg_final(const F128 *partials, uint32_t nparts, uint32_t len, F128 *out) {
-    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= len) return;
-    F128 acc = f_zero();
-    for (uint32_t q = 0; q < nparts; q++) acc = f_add(acc, partials[(uint64_t)q * len + e]);
-    out[e] = acc;
+// second pass over the partial sums: 16 columns per workgroup, 16 lanes down each column
+__global__ void __launch_bounds__(256) k_agg_final(const F128 *partials, uint32_t nparts, uint32_t len, F128 *out) {
+    __shared__ F128 red[256];
+    const uint32_t col = blockIdx.x * 16 + (threadIdx.x & 15), grp = threadIdx.x >> 4;
+    uint64_t lo = 0, hi = 0, ov = 0;
+    if (col < len)
+        for (uint32_t q = grp; q < nparts; q += 16) {
+            F128 v = partials[(uint64_t)q * len + col];
+            u128 s = (((u128)hi << 64) | lo) + f_u(v);
+            ov += s < f_u(v);
+            lo = (uint64_t)s; hi = (uint64_t)(s >> 64);
+        }
+    red[threadIdx.x] = f_reduce256(lo, hi, ov, 0);
+    __syncthreads();
+    for (uint32_t s = 8; s >= 1; s >>= 1) {
+        if (grp < s) red[threadIdx.x] = f_add(red[threadIdx.x], red[threadIdx.x + 16 * s]);
+        __syncthreads();
+    }
+    if (grp == 0 && col < len) out[col] = red[threadIdx.x];
 }
 
 // Heavy hitters (server-hh/src/main.rs:72-104, hhcore/src/bucket.rs:48-55): per-counter u32
