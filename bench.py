@@ -39,14 +39,15 @@ WORKLOADS = {
                       desc="Prio3 Histogram length=128 chunk_size=64, 100k clients"),
 }
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+KECCAK_PEAK = 10.6e9         # Keccak-f[1600]/s, measured permutation-only ceiling of this kernel style on MI355X
 
 
 def alg_bytes_per_report(s, role):
     """Algorithmic bytes each kernel must move for one report ('Kernels')."""
     IL, PL, VL, OL, C = s.input_len, s.proof_len, s.verifier_len, s.output_len, s.calls
     hash_rd = 16 * IL + 32 * PL + 32 * VL + 64 + 64 + 16 + 16 + 16 + 16     # absorbed bytes: meas, 2 proofs, pp, parts, blinds, nonce, id
-    hash_wr = 16 * (VL + 5) + 16 * (C + 1) + 112 + 16                        # rlc, weights, scalars, testing id
-    query_rd = 16 * IL + 16 * PL + 32 * VL + 16 * (VL + 5) + 16 * (C + 1) + 112 + (16 * PL if role == 0 else 0)
+    hash_wr = 16 * (VL + 5) + 16 * (C + 1) + 48 * C + 848 + 112 + 16         # rlc, weights, weight limbs, power tables, scalars, testing id
+    query_rd = 16 * IL + 16 * PL + 32 * VL + 16 * (VL + 5) + 48 * C + 848 + 112 + (16 * PL if role == 0 else 0)
     query_wr = 16 * OL + 16
     expand = (64 + 16 * (IL + 2 * PL)) if role == 1 else 0
     return {"expand": expand, "hash": hash_rd + hash_wr, "query": query_rd + query_wr, "parse": 64 + 56, "aggregate": 16 * OL + 1}
@@ -204,7 +205,11 @@ def main():
                          "note": "the verify kernels are integer-VALU bound (SHAKE128 + Field128), not HBM bound; see valu"},
             "valu": {"keccak_f1600_per_step": total_perms,
                      "keccak_f1600_per_s": total_perms * args.steps / elapsed,
-                     "note": "one Keccak-f[1600] is ~6.2k 32-bit VALU lane-ops; chip peak 256 CU x 128 lanes x 2.4 GHz = 78.6 T lane-ops/s"},
+                     "keccak_f1600_peak_per_s": KECCAK_PEAK,
+                     "frac": total_perms * args.steps / elapsed / KECCAK_PEAK,
+                     "note": "peak = tools/keccak_bench.hip on this chip (state in VGPRs, >= 3 waves/SIMD, profiles/r1_keccak_bench.txt); "
+                             "a round is 122 v_bitop3/v_xor (full rate) + 58 v_alignbit (half rate); frac counts the whole step "
+                             "(query and aggregation included) against the permutation-only peak"},
             "kernels": kernels,
         }
         if not args.no_cpu_baseline:
