@@ -147,6 +147,13 @@ int32_t wh_test_f128_op(wh_ctx *ctx, int32_t op, const uint8_t *a, const uint8_t
 int32_t wh_test_xof_expand(wh_ctx *ctx, const uint8_t *seeds, uint64_t n, uint32_t alg_id, uint32_t usage,
                            const uint8_t *binder, uint32_t binder_len, uint32_t n_elems, uint8_t *out);
 
+/* Test hook, no counterpart in the reference: the rejection sampler (prng.rs:73-99) skips 16-byte chunks >= p,
+ * which SHAKE output does with probability 2^-59 per element.  A bound below p (16 bytes, little endian) makes
+ * that branch run in every XOF of the protocol; NULL or a value >= p restores p.  The client generator has its
+ * own (process-wide) setting so that reports and verifier agree. */
+int32_t wh_ctx_set_test_sampler_bound(wh_ctx *ctx, const uint8_t bound[16]);
+void wh_client_set_test_sampler_bound(const uint8_t bound[16]);
+
 #ifdef __cplusplus
 }
 #endif

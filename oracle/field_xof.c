@@ -181,6 +181,15 @@ void xof_into_seed(shake_t *s, uint8_t out[16]) { shake_finalize(s); shake_squee
 /* prng.rs:73-99 + field.rs from_random_rejection: successive 16-byte chunks of the
  * stream, little-endian, chunks >= p are skipped.  (The 32-element buffer of the
  * reference is a multiple of 16 bytes, so chunk boundaries are those of the stream.) */
+/* Test hook (not in the reference): chunks >= wo_sampler_bound are skipped, default p.  With a
+ * bound below p the skip branch, which SHAKE output reaches with probability 2^-59 per element,
+ * runs for every XOF in the protocol; accepted values are still canonical field elements. */
+static u128 wo_sampler_bound = WO_P;
+void wo_set_test_sampler_bound(const uint8_t bound[16]) {
+    u128 v = 0;
+    if (bound) for (int i = 0; i < 16; i++) v |= (u128)bound[i] << (8 * i);
+    wo_sampler_bound = (bound && v <= WO_P) ? v : WO_P;
+}
 void xof_next_vec(shake_t *s, u128 *out, size_t n) {
     size_t got = 0;
     while (got < n) {
@@ -188,7 +197,7 @@ void xof_next_vec(shake_t *s, u128 *out, size_t n) {
         shake_squeeze(s, b, 16);
         u128 v = 0;
         for (int i = 0; i < 16; i++) v |= (u128)b[i] << (8 * i);
-        if (v >= WO_P) continue;
+        if (v >= wo_sampler_bound) continue;
         out[got++] = f_from_int(v);
     }
 }

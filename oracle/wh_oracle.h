@@ -80,6 +80,8 @@ void wo_shake128(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len)
 void wo_xof_expand_f128(const uint8_t seed[16], const uint8_t *dst, size_t dst_len,
                         const uint8_t *binder, size_t binder_len, size_t n, uint8_t *out);
 /* XofShake128 init/update(binder)/into_seed */
+/* test hook: rejection bound of the sampler (NULL or anything > p restores p) */
+void wo_set_test_sampler_bound(const uint8_t bound[16]);
 void wo_xof_derive_seed(const uint8_t seed[16], const uint8_t *dst, size_t dst_len,
                         const uint8_t *binder, size_t binder_len, uint8_t out[16]);
 /* discrete_fourier_transform (fft.rs:31-85) on n_in<=size inputs, canonical residues */

@@ -87,6 +87,11 @@ def shake128(data, n):
     o = _buf(n); _lib.wo_shake128(_b(data) if data else None, C.c_size_t(len(data)), o, C.c_size_t(n)); return bytes(o)
 
 
+def set_test_sampler_bound(bound=None):
+    """Test hook: chunks >= bound are skipped by the sampler (None restores p)."""
+    _lib.wo_set_test_sampler_bound(None if bound is None else _b(int(bound).to_bytes(16, "little")))
+
+
 def xof_expand(seed, dst, binder, n):
     o = _buf(16 * n)
     _lib.wo_xof_expand_f128(_b(seed), _b(dst), C.c_size_t(len(dst)), _b(binder) if binder else None,

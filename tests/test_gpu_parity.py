@@ -62,6 +62,47 @@ def test_xof_expand_bit_exact(small_ctx, n_elems, binder):
         assert out[i].tobytes() == O.xof_expand(seeds[i].tobytes(), dst, binder, n_elems)
 
 
+def test_sampler_rejection_branch_with_lowered_bound(small_ctx):
+    """prng.rs:73-99 skips chunks >= p; SHAKE output gets there with probability 2^-59.  With the test
+    bound at ~p/3 two of three chunks are skipped, in the XOF unit and in every XOF of a whole batch
+    (client generator, oracle and GPU all sample with the same bound)."""
+    bound = O.P128 // 3 + 12345
+    seeds = det(b"rej", 16 * 70).reshape(70, 16)
+    dst = bytes([7, 0, 0, 0, 0, 2, 0, 1])
+    p = W.Prio3Params(W.SUMVEC, 16, 16, 8)
+    op = O.params(W.SUMVEC, 16, 16, 8)
+    vdaf = W.Prio3(p)
+    try:
+        O.set_test_sampler_bound(bound)
+        small_ctx.set_test_sampler_bound(bound)
+        vdaf.set_test_sampler_bound(bound)
+        W.client_set_test_sampler_bound(bound)
+        for n_elems in (1, 10, 21, 64, 300):
+            out = small_ctx.test_xof_expand(seeds, 2, 1, b"\x01", n_elems)
+            for i in (0, 5, 69):
+                want = O.xof_expand(seeds[i].tobytes(), dst, b"\x01", n_elems)
+                assert out[i].tobytes() == want
+                assert all(int.from_bytes(want[16 * e:16 * e + 16], "little") < bound for e in range(n_elems))
+        n = 12
+        lr, hr, meas = make_reports(p, n, seed=77)
+        alice, bob = server_views(lr, hr, {3})
+        tags = []
+        for reports in (alice, bob):
+            t, ids, status = vdaf.prepare_encoded_keys(VK, reports)
+            outs = vdaf.out_shares()
+            o_t, o_ids, o_status, o_outs = oracle_batch(op, reports)
+            assert not status.any() and not o_status.any()
+            assert np.array_equal(t, o_t) and np.array_equal(ids, o_ids) and np.array_equal(outs, o_outs)
+            tags.append(t)
+        for i in range(n):
+            assert (tags[0][i].tobytes() != tags[1][i].tobytes()) == (i == 3)
+    finally:
+        O.set_test_sampler_bound(None)
+        small_ctx.set_test_sampler_bound(None)
+        W.client_set_test_sampler_bound(None)
+        vdaf.close()
+
+
 CASES = [
     ("sumvec_2_5_3", (W.SUMVEC, 2, 5, 3), 9),
     ("sumvec_ragged_16_3_7", (W.SUMVEC, 16, 3, 7), 8),
@@ -141,6 +182,31 @@ def test_prepare_and_aggregate_match_oracle(name, cfg, n):
         else:
             want = [int(sum(int(meas[i][0]) for i in good))]
         assert total == want
+    finally:
+        vdaf.close()
+
+
+def test_empty_and_all_malformed_batches():
+    """Edge cases of the batch boundary: no reports; only malformed reports; one report."""
+    p = W.Prio3Params(W.SUMVEC, 16, 16, 8)
+    op = O.params(W.SUMVEC, 16, 16, 8)
+    vdaf = W.Prio3(p)
+    try:
+        tags, ids, status = vdaf.prepare_encoded_keys(VK, [])
+        assert tags.shape == (0, 16) and status.shape == (0,)
+        assert vdaf.aggregate(None).tobytes() == bytes(16 * p.sizes.output_len)
+        lr, hr, _ = make_reports(p, 2, seed=3)
+        junk = [b"", b"\x00" * 48, lr[0].tobytes()[:100], hr[0].tobytes()[:-1]]
+        tags, ids, status = vdaf.prepare_encoded_keys(VK, junk)
+        o_tags, o_ids, o_status, o_outs = oracle_batch(op, junk)
+        assert np.array_equal(status, o_status) and (status != 0).all()
+        assert not tags.any() and not vdaf.out_shares().any()
+        assert vdaf.aggregate(None).tobytes() == bytes(16 * p.sizes.output_len)
+        one = [hr[1].tobytes()]
+        tags, ids, status = vdaf.prepare_encoded_keys(VK, one)
+        o_tags, o_ids, o_status, o_outs = oracle_batch(op, one)
+        assert not status.any() and np.array_equal(tags, o_tags) and np.array_equal(ids, o_ids)
+        assert np.array_equal(vdaf.aggregate(None), O.prio3_aggregate(o_outs, p.sizes.output_len, np.ones(1, np.uint8)))
     finally:
         vdaf.close()
 

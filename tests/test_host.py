@@ -10,7 +10,7 @@ import pytest
 
 import oracle_lib as O
 import whisper_amd as W
-from common import make_reports, det
+from common import VK, make_reports, det
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -55,6 +55,34 @@ def test_client_matches_oracle_sharder(circ, bits, ln, ch):
         l2, h2 = O.prio3_shard_batched(op, [int(x) for x in meas[i]], nonces[i].tobytes(), rands[i].tobytes(), 2**40 + 3 + i)
         assert lr[i].tobytes() == l2
         assert hr[i].tobytes() == h2
+
+
+def test_sampler_skip_branch_client_and_oracle_agree():
+    """The sampler's skip branch (prng.rs:73-99) with the test bound lowered to ~p/3: the CPU client
+    and the oracle's sharder still agree byte for byte, and the oracle's two aggregators still get
+    tags that cancel (vdaf.rs:889-897)."""
+    bound = O.P128 // 3 + 999
+    p = W.Prio3Params(0, 16, 16, 8)
+    op = O.params(0, 16, 16, 8)
+    try:
+        O.set_test_sampler_bound(bound)
+        W.client_set_test_sampler_bound(bound)
+        lr, hr, meas = make_reports(p, 3, seed=9, first_client_id=77, nthreads=2)
+        nonces = det(b"nonce9", 48).reshape(3, 16)
+        rands = det(b"rand9", 432).reshape(3, 144)
+        for i in range(3):
+            l2, h2 = O.prio3_shard_batched(op, [int(x) for x in meas[i]], nonces[i].tobytes(), rands[i].tobytes(), 77 + i)
+            assert lr[i].tobytes() == l2 and hr[i].tobytes() == h2
+            ta, _, sa, _ = O.prio3_prepare_batch(op, VK, np.frombuffer(l2, np.uint8), np.array([0, len(l2)], np.uint64))
+            tb, _, sb, _ = O.prio3_prepare_batch(op, VK, np.frombuffer(h2, np.uint8), np.array([0, len(h2)], np.uint64))
+            assert not sa.any() and not sb.any() and ta.tobytes() == tb.tobytes()
+        # and the unlowered reports differ (the hook really changes the stream)
+        O.set_test_sampler_bound(None)
+        l3, _ = O.prio3_shard_batched(op, [int(x) for x in meas[0]], nonces[0].tobytes(), rands[0].tobytes(), 77)
+        assert l3 != lr[0].tobytes()
+    finally:
+        O.set_test_sampler_bound(None)
+        W.client_set_test_sampler_bound(None)
 
 
 def test_group_testing_mirror():

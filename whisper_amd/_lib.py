@@ -39,6 +39,7 @@ EXPORTS = [
     "wh_prio3_aggregate_dev", "wh_prio3_aggregate", "wh_f128_sum_rows_dev", "wh_hh_bucket_sum_u32_dev",
     "wh_ctx_synchronize", "wh_client_shard_batched", "wh_client_shard_many", "wh_test_f128_op",
     "wh_test_xof_expand", "wh_ctx_set_profiling", "wh_ctx_kernel_times",
+    "wh_ctx_set_test_sampler_bound", "wh_client_set_test_sampler_bound",
 ]
 
 vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32
@@ -64,7 +65,10 @@ lib.wh_ctx_set_profiling.argtypes = [vp, i32]
 lib.wh_ctx_kernel_times.argtypes = [vp, vp, vp, i32]
 lib.wh_test_f128_op.argtypes = [vp, i32, vp, vp, vp, u64]
 lib.wh_test_xof_expand.argtypes = [vp, vp, u64, u32, u32, vp, u32, u32, vp]
+lib.wh_ctx_set_test_sampler_bound.argtypes = [vp, vp]
+lib.wh_client_set_test_sampler_bound.argtypes = [vp]
+lib.wh_client_set_test_sampler_bound.restype = None
 for _n in EXPORTS:
     getattr(lib, _n)  # AttributeError here = the library does not export what the header declares
-    if _n not in ("wh_ctx_destroy", "wh_last_error", "wh_ctx_stream"):
+    if _n not in ("wh_ctx_destroy", "wh_last_error", "wh_ctx_stream", "wh_client_set_test_sampler_bound"):
         getattr(lib, _n).restype = i32

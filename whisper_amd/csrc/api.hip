@@ -200,6 +200,7 @@ int32_t wh_ctx_create(int32_t device_id, const wh_prio3_params *params, wh_ctx *
     P.alg_id = z.alg_id; P.leader_len = z.leader_len; P.helper_len = z.helper_len; P.n_weights = z.calls + 1;
     P.half = f_inv(f_small(2));
     P.m_inv = f_inv(f_small(z.m));
+    P.sampler_bound = F128{P_LO, P_HI};
     P.omega = c->d_omega; P.s_tab = c->d_stab;
     *out = c;
     return WH_OK;
@@ -423,6 +424,18 @@ int32_t wh_ctx_kernel_times(wh_ctx *c, double *ms, uint64_t *launches, int32_t r
     return WH_OK;
 }
 
+int32_t wh_ctx_set_test_sampler_bound(wh_ctx *c, const uint8_t bound[16]) {
+    if (!c) return WH_ERR_PARAM;
+    F128 b = F128{P_LO, P_HI};
+    if (bound) {
+        F128 v;
+        memcpy(&v, bound, 16);
+        if (f_in_range(v.lo, v.hi)) b = v;
+    }
+    c->P.sampler_bound = b;
+    return WH_OK;
+}
+
 int32_t wh_test_f128_op(wh_ctx *c, int32_t op, const uint8_t *a, const uint8_t *b, uint8_t *out, uint64_t n) {
     if (!c || !a || !out || !n) return WH_ERR_PARAM;
     HIPCHK(c, hipSetDevice(c->device));
@@ -446,7 +459,7 @@ int32_t wh_test_xof_expand(wh_ctx *c, const uint8_t *seeds, uint64_t n, uint32_t
     HIPCHK(c, hipMalloc((void **)&dout, 16ull * n_elems * n));
     HIPCHK(c, hipMemcpy(ds, seeds, 16 * n, hipMemcpyHostToDevice));
     if (binder_len) HIPCHK(c, hipMemcpy(db, binder, binder_len, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_test_xof, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, c->stream, ds, alg_id, usage, db, binder_len, n_elems, dout, (uint32_t)n);
+    hipLaunchKernelGGL(k_test_xof, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, c->stream, ds, alg_id, usage, db, binder_len, n_elems, dout, (uint32_t)n, c->P.sampler_bound);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, dout, 16ull * n_elems * n, hipMemcpyDeviceToHost));
     hipFree(ds); hipFree(db); hipFree(dout);

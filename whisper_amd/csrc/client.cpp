@@ -16,13 +16,16 @@ namespace {
 
 typedef std::vector<F128> Vec;
 
+// sampler bound: p, unless a test lowered it (wh_client_set_test_sampler_bound)
+F128 g_sampler_bound = F128{P_LO, P_HI};
+
 Vec expand(uint32_t alg, uint32_t usage, const uint8_t *seed, const uint8_t *binder, uint32_t blen, uint32_t n) {
     Sponge s;
     s.init_xof(alg, usage, seed);
     if (blen) s.absorb(binder, blen);
     s.finalize();
     Vec out(n);
-    xof_emit(s, reinterpret_cast<uint8_t *>(out.data()), n);
+    xof_emit(s, reinterpret_cast<uint8_t *>(out.data()), n, g_sampler_bound);
     return out;
 }
 F128 derive_seed(uint32_t alg, const F128 parts[2]) {
@@ -243,4 +246,15 @@ extern "C" int32_t wh_client_shard_many(const wh_prio3_params *params, const uin
     for (auto &x : th) x.join();
     for (int32_t r : rcs) if (r) return r;
     return WH_OK;
+}
+
+extern "C" void wh_client_set_test_sampler_bound(const uint8_t bound[16]) {
+    using namespace wh;
+    F128 b = F128{P_LO, P_HI};
+    if (bound) {
+        F128 v;
+        memcpy(&v, bound, 16);
+        if (f_in_range(v.lo, v.hi)) b = v;
+    }
+    g_sampler_bound = b;
 }

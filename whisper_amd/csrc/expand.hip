@@ -27,7 +27,7 @@ __global__ void __launch_bounds__(256) k_expand(Prio3Dev P, Workspace W, uint32_
         s.init_xof(P.alg_id, which ? DST_PROOF : DST_MEAS, seed);
         s.absorb3(d.base + 48, 1, nullptr, 0, nullptr, 0);   // binder = [agg_id]
         s.finalize();
-        xof_emit(s, out, which ? P.proof_len : P.input_len);
+        xof_emit(s, out, which ? P.proof_len : P.input_len, P.sampler_bound);
     }
 }
 

@@ -287,12 +287,13 @@ struct Sponge {
 // Prng::get over a finalized sponge (prng.rs:73-99): consecutive 16-byte chunks of the output
 // stream, little endian, chunks >= p skipped; writes `n` elements (16 B each) at `out`.
 // Two rate blocks hold exactly 21 chunks, so the loop below is the whole stream walk.
-WH_HD void xof_emit(Sponge &s, uint8_t *out, uint32_t n) {
+// `bound` is p everywhere except under the test hook wh_*_set_test_sampler_bound.
+WH_HD void xof_emit(Sponge &s, uint8_t *out, uint32_t n, const F128 &bound) {
     uint32_t left = n;
 #define WH_EMIT(lo_, hi_)                                                                      \
     do {                                                                                         \
         uint64_t l_ = (lo_), h_ = (hi_);                                                         \
-        if (left && f_in_range(l_, h_)) { st128(out, F128{l_, h_}); out += 16; left--; }         \
+        if (left && (h_ < bound.hi || (h_ == bound.hi && l_ < bound.lo))) { st128(out, F128{l_, h_}); out += 16; left--; } \
     } while (0)
     for (;;) {
         // even block: chunks (0,1) .. (18,19); word 20 is the low half of a straddling chunk

@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(256) k_hash(Prio3Dev P, Workspace W, uint32_t 
         s.absorb3(p1, l1, p2, l2, p3, l3);
         s.finalize();
         if (emit_n) {
-            xof_emit(s, emit_p, emit_n);
+            xof_emit(s, emit_p, emit_n, P.sampler_bound);
         } else {
             sd = F128{s.st[0], s.st[1]};          // Xof::into_seed
             if (!which && (stg == 0 || stg == 3)) {
@@ -826,14 +826,14 @@ __global__ void k_test_f128(const F128 *a, const F128 *b, F128 *out, uint32_t n,
 }
 // XofShake128::seed_stream(seed, dst(alg_id, usage), binder).into_field_vec(n) per lane
 __global__ void __launch_bounds__(64) k_test_xof(const uint8_t *seeds, uint32_t alg_id, uint32_t usage, const uint8_t *binder,
-                           uint32_t binder_len, uint32_t n_elems, uint8_t *out, uint32_t n) {
+                           uint32_t binder_len, uint32_t n_elems, uint8_t *out, uint32_t n, F128 bound) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Sponge s;
     s.init_xof(alg_id, usage, seeds + 16ull * i);
     s.absorb(binder, binder_len);
     s.finalize();
-    xof_emit(s, out + 16ull * n_elems * i, n_elems);
+    xof_emit(s, out + 16ull * n_elems * i, n_elems, bound);
 }
 
 }  // namespace wh

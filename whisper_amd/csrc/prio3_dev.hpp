@@ -30,6 +30,7 @@ struct Prio3Dev {
     uint32_t n_weights;               // calls + 1
     F128 half;                        // num_shares^-1 = 2^-1
     F128 m_inv;                       // m^-1
+    F128 sampler_bound;               // p (test hook: a smaller bound makes the sampler's skip branch run)
     const F128 *omega;                // omega_m^j, j = 0..m-1 (device)
     const F128 *s_tab;                // sum_{j=1..calls} omega_m^{ij}, i = 0..gpoly_len-1 (device)
 };

@@ -34,6 +34,12 @@ def _ptr(a):
     return None if a is None else a.ctypes.data
 
 
+def client_set_test_sampler_bound(bound=None):
+    """Test hook for the CPU client generator (process-wide), see Prio3.set_test_sampler_bound."""
+    b = None if bound is None else np.frombuffer(int(bound).to_bytes(16, "little"), np.uint8).copy()
+    lib.wh_client_set_test_sampler_bound(None if b is None else b.ctypes.data)
+
+
 def shard_batched_many(params, measurements, nonces, rands, first_client_id=0, nthreads=8):
     """CPU client: client-batch-prio3/src/main.rs:67-153 for n clients.
 
@@ -164,6 +170,11 @@ class Prio3:
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.KERNELS)}
 
     # ---- unit-parity surface ----
+    def set_test_sampler_bound(self, bound=None):
+        """Test hook: lower the rejection bound of the sampler (int < p), None restores p."""
+        b = None if bound is None else np.frombuffer(int(bound).to_bytes(16, "little"), np.uint8).copy()
+        self._chk(lib.wh_ctx_set_test_sampler_bound(self._ctx, None if b is None else b.ctypes.data), "set_test_sampler_bound")
+
     def test_f128_op(self, op, a, b=None):
         a = np.ascontiguousarray(a, dtype=np.uint8)
         n = a.size // 16
