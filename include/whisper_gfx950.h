@@ -27,14 +27,17 @@ enum { WH_SUMVEC = 0, WH_HISTOGRAM = 1, WH_AVERAGE = 2 };
 
 /* Instance parameters: the arguments of Prio3::new_sum_vec_256 / new_histogram_256 /
  * new_average_256 (vdaf/prio3.rs:150-165, 300-313, 360-380) as the servers call them
- * (server-batch-prio3/src/main.rs:249-257).  num_aggregators must be 2 (Alice and Bob). */
+ * (server-batch-prio3/src/main.rs:249-257).  The batched path needs num_aggregators == 2 (Alice and
+ * Bob); the draft-07 prepare_init path takes 2..255. */
 typedef struct {
     uint32_t circuit;         /* WH_SUMVEC | WH_HISTOGRAM | WH_AVERAGE */
     uint32_t bits;            /* SumVec: 16 in the servers; Average: AVG_BITS = 64 */
     uint32_t len;             /* SumVec vec_size / Histogram length */
     uint32_t chunk;           /* chunk_size */
     uint32_t num_aggregators; /* 2 */
-    uint32_t reserved;        /* 0 */
+    uint32_t alg_id;          /* 0 = the circuit's own algorithm id (types.rs:577,383,242); otherwise the
+                               * `Type::ID` to bind into every XOF, e.g. 1 to run Average's circuit as
+                               * draft-07 Prio3Sum (types.rs:142-208) */
 } wh_prio3_params;
 
 /* Derived sizes (flp/types.rs:650-676, 444-470, 286-312; report sizes from vdaf.rs:148-162). */
@@ -54,6 +57,8 @@ enum {
     WH_ERR_AGG_ID = -4,       /* "unexpected aggregator id" (prio3.rs:1496-1501) */
     WH_ERR_NUM_QUERIES = -5,  /* public proof length != verifier length (prio3.rs:2712) */
     WH_ERR_QUERY_RAND = -6,   /* FlpError::Query: r is an m-th root of unity (flp.rs:413-419) */
+    WH_ERR_DECIDE = -7,       /* "proof verifier check failed" (prio3.rs:2372-2378) */
+    WH_ERR_JOINT_RAND = -8,   /* "joint randomness mismatch" (prio3.rs:2414-2420) */
     /* library-level */
     WH_ERR_HIP = -100,
     WH_ERR_NO_DEVICE = -101,
@@ -94,6 +99,29 @@ int32_t wh_prio3_prepare_batch(wh_ctx *ctx, const uint8_t verify_key[16], const 
 /* replaces: Prio3::prepare_batched's second return value (OutputShare).  Copies the n*output_len
  * out-share elements of the last batch to the host. */
 int32_t wh_prio3_out_shares(wh_ctx *ctx, uint8_t *out_shares);
+
+/* ---- un-batched Prio3 (draft-07), the paper's baseline server ---- */
+/* replaces: the first map of server-base-prio3's run_vdaf_prepare (server-base-prio3/src/main.rs:41-61) =
+ *   VdafKey::decode_with_param (vdaf.rs:219-233) + Prio3::prepare_init (vdaf/prio3.rs:2216-2345)
+ *   + Prio3PrepareShare::get_encoded (prio3.rs:1953-1970).
+ * blob/offsets: n encoded VdafKeys: agg_id u8 | num_aggregators joint-rand parts | input share | nonce[16].
+ *   prep_shares  n * (verifier_len + 1) * 16   verifier share | own joint-rand part, per report
+ *   status       n
+ * The prepare state (out share = truncated measurement share, joint-rand seed) stays in the context. */
+int32_t wh_prio3_prepare_init_batch_dev(wh_ctx *ctx, const uint8_t verify_key[16], const uint8_t *d_blob,
+                                        const uint64_t *d_offsets, uint64_t n, uint8_t *d_prep_shares,
+                                        int32_t *d_status);
+int32_t wh_prio3_prepare_init_batch(wh_ctx *ctx, const uint8_t verify_key[16], const uint8_t *blob,
+                                    const uint64_t *offsets, uint64_t n, uint8_t *prep_shares, int32_t *status);
+/* replaces: the second map of run_vdaf_prepare (main.rs:68-100) =
+ *   prepare_shares_to_prepare_message (prio3.rs:2347-2394: sum of the verifier shares, Type::decide,
+ *   joint-rand seed from the parts) + prepare_next (:2396-2442: seed check; the out share is the state's).
+ * prep_shares[a] = aggregator a's n prepare shares in agg_id order (one of them is this context's own output
+ * of the last prepare_init batch).  prep_msgs: n * 16 (the joint-rand seed).  status: per report, WH_ERR_DECIDE /
+ * WH_ERR_JOINT_RAND for rejected reports; reports that already failed keep their status.  Afterwards
+ * wh_prio3_out_shares / wh_prio3_aggregate* see only the accepted reports. */
+int32_t wh_prio3_prepare_finish_batch(wh_ctx *ctx, const uint8_t *const *prep_shares, uint64_t n, uint8_t *prep_msgs,
+                                      int32_t *status);
 
 /* ---- aggregation ---- */
 /* replaces: the merge loop over reports whose testing id is not in the bad set

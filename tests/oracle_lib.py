@@ -149,6 +149,12 @@ def flp_truncate(p, inp):
     return bytes(o)
 
 
+def prio3_rand_size(p):
+    """Prio3::random_size with joint randomness (prio3.rs:495-513): per Helper two share seeds and a blind,
+    the Leader's blind, the prove-rand seed."""
+    return 16 * (3 * (p.num_aggregators - 1) + 2)
+
+
 def prio3_shard(p, meas, nonce, rand):
     s = sizes(p); na = p.num_aggregators
     ps = _buf(16 * na); ls = _buf(16 * (s.input_len + s.proof_len) + 16); hs = _buf(48 * (na - 1))

@@ -1,0 +1,133 @@
+"""GPU parity for the un-batched (draft-07) Prio3 path, SURVEY section 8(f) row 3: prepare_init /
+prepare_next through the C ABI against the reference's own golden vectors (tests/golden/draft07, copied as
+data from batched-flpcp-rs/src/vdaf/test_vec/07/) and against the oracle on seeded inputs.  Bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import whisper_amd as W
+from common import det
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "draft07")
+
+VECTORS = ["Prio3SumVec_0.json", "Prio3SumVec_1.json", "Prio3Histogram_0.json", "Prio3Histogram_1.json",
+           "Prio3Sum_0.json", "Prio3Sum_1.json"]
+
+
+def params_for(name, v):
+    na = v["shares"]
+    if name.startswith("Prio3SumVec"):
+        return (W.Prio3Params(W.SUMVEC, v["bits"], v["length"], v["chunk_length"], na),
+                O.params(O.SUMVEC, v["bits"], v["length"], v["chunk_length"], na))
+    if name.startswith("Prio3Histogram"):
+        return (W.Prio3Params(W.HISTOGRAM, 0, v["length"], v["chunk_length"], na),
+                O.params(O.HISTOGRAM, 0, v["length"], v["chunk_length"], na))
+    # Prio3Sum: Average's circuit bound to algorithm id 1 (types.rs:142-208 vs 241-313)
+    return (W.Prio3Params(W.AVERAGE, v["bits"], 0, 0, na, alg_id=1), O.params(O.AVERAGE, v["bits"], 0, 0, na, alg_id=1))
+
+
+@pytest.mark.parametrize("name", VECTORS)
+def test_prepare_init_reproduces_draft07_vectors(name):
+    v = json.load(open(os.path.join(GOLD, name)))
+    p, _ = params_for(name, v)
+    vk = bytes.fromhex(v["verify_key"])
+    na = v["shares"]
+    vdaf = W.Prio3(p)
+    try:
+        preps = v["prep"]
+        per_agg_prep, per_agg_out = [], []
+        for agg_id in range(na):
+            keys = [W.Prio3.encode_vdaf_key(agg_id, bytes.fromhex(t["public_share"]), bytes.fromhex(t["input_shares"][agg_id]),
+                                            bytes.fromhex(t["nonce"])) for t in preps]
+            prep, status = vdaf.prepare_init_encoded_keys(vk, keys)
+            assert not status.any()
+            outs = vdaf.out_shares()
+            for j, t in enumerate(preps):
+                assert prep[j].tobytes().hex() == t["prep_shares"][0][agg_id]
+                assert [outs[j][16 * e:16 * e + 16].tobytes().hex() for e in range(p.output_len)] == t["out_shares"][agg_id]
+            assert vdaf.aggregate(None).tobytes().hex() == v["agg_shares"][agg_id]
+            per_agg_prep.append(prep)
+            per_agg_out.append(outs)
+        # prepare_shares_to_prepare_message + prepare_next, with the last aggregator's state in the context
+        msgs, status = vdaf.prepare_finish(per_agg_prep)
+        assert not status.any()
+        for j, t in enumerate(preps):
+            assert msgs[j].tobytes().hex() == t["prep_messages"][0]
+        # a verifier share that does not belong makes decide fail; a foreign joint-rand part the seed check
+        bad = [a.copy() for a in per_agg_prep]
+        bad[0][0, 20] ^= 1
+        _, status = vdaf.prepare_finish(bad)
+        assert status[0] == -7 and not status[1:].any()
+    finally:
+        vdaf.close()
+
+
+CASES = [
+    ("sumvec_16_16_8", (W.SUMVEC, 16, 16, 8), 2, 9),
+    ("sumvec_cfg1", (W.SUMVEC, 16, 128, 64), 2, 66),
+    ("sumvec_chunk128_three", (W.SUMVEC, 16, 64, 128), 3, 5),
+    ("sumvec_ragged", (W.SUMVEC, 8, 40, 5), 2, 5),
+    ("histogram_128_64", (W.HISTOGRAM, 0, 128, 64), 2, 10),
+    ("average_64", (W.AVERAGE, 64, 0, 0), 2, 10),
+]
+
+
+def measurement_for(circ, bits, ln, i):
+    if circ == W.SUMVEC:
+        r = np.frombuffer(det(b"pm%d" % i, 8 * ln), dtype=np.uint64)
+        return [int(x) & ((1 << min(bits, 16)) - 1) for x in r]
+    if circ == W.HISTOGRAM:
+        return [i % ln]
+    return [int.from_bytes(det(b"pm%d" % i, 8), "little") & 0xFFFF]
+
+
+@pytest.mark.parametrize("name,cfg,na,n", CASES, ids=[c[0] for c in CASES])
+def test_prepare_init_matches_oracle(name, cfg, na, n):
+    circ, bits, ln, ch = cfg
+    p = W.Prio3Params(circ, bits, ln, ch, na)
+    op = O.params(circ, bits, ln, ch, na)
+    vk = bytes(det(b"vk" + name.encode(), 16))
+    shards = []
+    for i in range(n):
+        nonce = bytes(det(b"n%d" % i, 16))
+        rand = bytes(det(b"r%d" % i, O.prio3_rand_size(op)))
+        public_share, input_shares = O.prio3_shard(op, measurement_for(circ, bits, ln, i), nonce, rand)
+        shards.append((nonce, public_share, input_shares))
+    vdaf = W.Prio3(p)
+    try:
+        all_prep = []
+        for agg_id in range(na):
+            keys = [W.Prio3.encode_vdaf_key(agg_id, ps, ish[agg_id], nonce) for nonce, ps, ish in shards]
+            # malformed keys: short, bad aggregator id, element >= p (Leader only)
+            extra = [keys[0][:-1], bytes([na]) + keys[0][1:]]
+            if agg_id == 0:
+                x = bytearray(keys[1]); off = 1 + 16 * na; x[off:off + 16] = O.P128.to_bytes(16, "little"); extra.append(bytes(x))
+            prep, status = vdaf.prepare_init_encoded_keys(vk, keys + extra)
+            outs = vdaf.out_shares()
+            assert list(status[n:]) == ([-2, -4, -3] if agg_id == 0 else [-2, -4])
+            assert not prep[n:].any() and not outs[n:].any()
+            for j, (nonce, ps, ish) in enumerate(shards):
+                rc, want_prep, want_out = O.prio3_prepare_init(op, vk, agg_id, nonce, ps, ish[agg_id])
+                assert rc == 0 and status[j] == 0
+                assert prep[j].tobytes() == want_prep
+                assert outs[j].tobytes() == want_out
+            prep, status = vdaf.prepare_init_encoded_keys(vk, keys)      # the state the finish step uses
+            all_prep.append(prep)
+        msgs, status = vdaf.prepare_finish(all_prep)
+        assert not status.any()
+        # tampered nonce on the last aggregator's copy: its joint randomness differs, decide fails
+        nonce, ps, ish = shards[0]
+        bad_key = W.Prio3.encode_vdaf_key(na - 1, ps, ish[na - 1], bytes([nonce[0] ^ 1]) + nonce[1:])
+        keys = [bad_key] + [W.Prio3.encode_vdaf_key(na - 1, ps2, ish2[na - 1], n2) for n2, ps2, ish2 in shards[1:]]
+        prep, status = vdaf.prepare_init_encoded_keys(vk, keys)
+        assert not status.any()
+        _, status = vdaf.prepare_finish(all_prep[:-1] + [prep])
+        assert status[0] in (-7, -8) and not status[1:].any()
+        keep = np.ones(n, np.uint8)
+        assert vdaf.aggregate(keep).tobytes() == O.prio3_aggregate(vdaf.out_shares()[1:], p.output_len).tobytes()
+    finally:
+        vdaf.close()

@@ -41,7 +41,11 @@ def test_sizes_match_oracle():
     with pytest.raises(W.WhError):
         W.Prio3Params(0, 16, 0, 4)
     with pytest.raises(W.WhError):
-        W.Prio3Params(0, 16, 4, 4, num_aggregators=3)
+        W.Prio3Params(0, 16, 4, 4, num_aggregators=1)
+    # three aggregators exist for the draft-07 prepare_init path only; the batched client refuses them
+    p3 = W.Prio3Params(0, 16, 4, 4, num_aggregators=3)
+    with pytest.raises(W.WhError):
+        make_reports(p3, 1, seed=1)
 
 
 @pytest.mark.parametrize("circ,bits,ln,ch", [(0, 2, 5, 3), (0, 16, 3, 7), (0, 16, 16, 8), (1, 0, 4, 2), (1, 0, 11, 3), (2, 64, 0, 0), (2, 8, 0, 0)])

@@ -24,7 +24,7 @@ class WhError(RuntimeError):
 
 class Params(C.Structure):
     _fields_ = [("circuit", C.c_uint32), ("bits", C.c_uint32), ("len", C.c_uint32), ("chunk", C.c_uint32),
-                ("num_aggregators", C.c_uint32), ("reserved", C.c_uint32)]
+                ("num_aggregators", C.c_uint32), ("alg_id", C.c_uint32)]
 
 
 class Sizes(C.Structure):
@@ -40,6 +40,7 @@ EXPORTS = [
     "wh_ctx_synchronize", "wh_client_shard_batched", "wh_client_shard_many", "wh_test_f128_op",
     "wh_test_xof_expand", "wh_ctx_set_profiling", "wh_ctx_kernel_times",
     "wh_ctx_set_test_sampler_bound", "wh_client_set_test_sampler_bound",
+    "wh_prio3_prepare_init_batch_dev", "wh_prio3_prepare_init_batch", "wh_prio3_prepare_finish_batch",
 ]
 
 vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32
@@ -65,6 +66,9 @@ lib.wh_ctx_set_profiling.argtypes = [vp, i32]
 lib.wh_ctx_kernel_times.argtypes = [vp, vp, vp, i32]
 lib.wh_test_f128_op.argtypes = [vp, i32, vp, vp, vp, u64]
 lib.wh_test_xof_expand.argtypes = [vp, vp, u64, u32, u32, vp, u32, u32, vp]
+lib.wh_prio3_prepare_init_batch_dev.argtypes = [vp, vp, vp, vp, u64, vp, vp]
+lib.wh_prio3_prepare_init_batch.argtypes = [vp, vp, vp, vp, u64, vp, vp]
+lib.wh_prio3_prepare_finish_batch.argtypes = [vp, vp, u64, vp, vp]
 lib.wh_ctx_set_test_sampler_bound.argtypes = [vp, vp]
 lib.wh_client_set_test_sampler_bound.argtypes = [vp]
 lib.wh_client_set_test_sampler_bound.restype = None

@@ -35,6 +35,7 @@ struct wh_ctx {
     uint8_t *d_blob = nullptr; uint64_t blob_cap = 0;
     uint64_t *d_offsets = nullptr; uint64_t off_cap = 0;
     uint8_t *d_tags = nullptr, *d_ids = nullptr; uint64_t tags_cap = 0, ids_cap = 0;
+    uint8_t *d_prep = nullptr; uint64_t prep_cap = 0;
     // optional per-kernel timing with HIP events on the context stream (wh_ctx_set_profiling)
     bool profiling = false;
     struct Ev { hipEvent_t a, b; int id; };
@@ -146,6 +147,26 @@ uint64_t pick_cap(const wh_ctx *c, uint64_t n) {
     return (n + parts - 1) / parts;
 }
 
+// query launch shape.  Average: four reports (wavefronts) per workgroup.  ParallelSum circuits:
+// one workgroup per report, one wavefront per 64 gadget slots (at most four); LDS holds 48 B of
+// weight limbs per gadget call, the hand-over area and the truncate staging of each wave.
+typedef void (*query_fn)(Prio3Dev, Workspace, uint8_t *, uint8_t *, int32_t *);
+struct QueryLaunch { query_fn fn; uint32_t waves; size_t lds; bool polyeval; };
+QueryLaunch query_launch(const wh_ctx *c, bool base) {
+    const HostSizes &z = c->z;
+    QueryLaunch q;
+    q.polyeval = c->params.circuit == WH_AVERAGE;
+    q.waves = q.polyeval ? 4 : (c->params.chunk <= 64 ? 1 : (c->params.chunk <= 128 ? 2 : 4));
+    q.lds = q.polyeval ? 4 * (size_t)z.m * sizeof(F128)
+                       : 48 * (size_t)z.calls + sizeof(QueryShared) + q.waves * (size_t)QT_STAGE_U4 * 16;
+    const bool hist = c->params.circuit == WH_HISTOGRAM;
+    if (q.polyeval) q.fn = base ? k_query_polyeval<true> : k_query_polyeval<false>;
+    else if (base) q.fn = hist ? k_query_psum<true, true> : k_query_psum<false, true>;
+    else q.fn = hist ? k_query_psum<true, false> : k_query_psum<false, false>;
+    if (q.lds > 64 * 1024) q.fn = nullptr;
+    return q;
+}
+
 }  // namespace
 
 extern "C" {
@@ -198,7 +219,8 @@ int32_t wh_ctx_create(int32_t device_id, const wh_prio3_params *params, wh_ctx *
     P.input_len = z.input_len; P.proof_len = z.proof_len; P.verifier_len = z.verifier_len; P.output_len = z.output_len;
     P.jr_len = z.jr_len; P.calls = z.calls; P.m = z.m; P.log2m = z.log2m; P.arity = z.arity; P.gpoly_len = z.gpoly_len;
     P.alg_id = z.alg_id; P.leader_len = z.leader_len; P.helper_len = z.helper_len; P.n_weights = z.calls + 1;
-    P.half = f_inv(f_small(2));
+    P.num_aggregators = params->num_aggregators; P.mode = 0;
+    P.half = f_inv(f_small(params->num_aggregators));
     P.m_inv = f_inv(f_small(z.m));
     P.sampler_bound = F128{P_LO, P_HI};
     P.omega = c->d_omega; P.s_tab = c->d_stab;
@@ -211,7 +233,7 @@ void wh_ctx_destroy(wh_ctx *c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->d_omega, c->d_stab, c->d_aes, c->d_out_shares, c->d_status_own, c->d_keep_eff, c->d_partials,
-                    c->d_blob, c->d_offsets, c->d_tags, c->d_ids, c->W.desc, c->W.scal, c->W.weights, c->W.wlimbs, c->W.pows, c->W.rlc,
+                    c->d_blob, c->d_offsets, c->d_tags, c->d_ids, c->d_prep, c->W.desc, c->W.scal, c->W.weights, c->W.wlimbs, c->W.pows, c->W.rlc,
                     c->W.hrows, c->W.hlist, c->W.llist, c->W.counters};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -232,10 +254,11 @@ int32_t wh_prio3_prepare_batch_dev(wh_ctx *c, const uint8_t verify_key[16], cons
                                    const uint64_t *d_offsets, uint64_t n, uint8_t *d_tags, uint8_t *d_ids,
                                    int32_t *d_status) {
     if (!c || !verify_key || (n && (!d_blob || !d_offsets || !d_tags || !d_ids || !d_status))) return WH_ERR_PARAM;
-    if (n > 0xfffffff0ull) return WH_ERR_PARAM;
+    if (n > 0xfffffff0ull || c->params.num_aggregators != 2) return WH_ERR_PARAM;
     HIPCHK(c, hipSetDevice(c->device));
     const HostSizes &z = c->z;
     int32_t rc;
+    c->P.mode = 0;
     // allocations first (none inside the launch sequence once the context is warm)
     if ((rc = alloc_workspace(c, pick_cap(c, n)))) return rc;
     if ((rc = ensure(c, c->d_out_shares, c->out_cap, (n ? n : 1) * (uint64_t)z.output_len))) return rc;
@@ -251,17 +274,8 @@ int32_t wh_prio3_prepare_batch_dev(wh_ctx *c, const uint8_t verify_key[16], cons
     memcpy(&vk0, verify_key, 8); memcpy(&vk1, verify_key + 8, 8);
     c->n_last = n;
     c->d_status_last = d_status;
-    const bool polyeval = c->params.circuit == WH_AVERAGE;
-    // query launch shape.  Average: four reports (wavefronts) per workgroup.  ParallelSum circuits:
-    // one workgroup per report, one wavefront per 64 gadget slots (at most four), 48 B of weight
-    // limbs per gadget call in LDS plus the hand-over area.
-    const uint32_t qwaves = polyeval ? 4 : (c->params.chunk <= 64 ? 1 : (c->params.chunk <= 128 ? 2 : 4));
-    const size_t lds = polyeval ? 4 * (size_t)z.m * sizeof(F128)
-                                : 48 * (size_t)z.calls + sizeof(QueryShared) + qwaves * (size_t)QT_STAGE_U4 * 16;
-    if (lds > 64 * 1024) { c->err = "circuit has too many gadget calls for the query kernel's LDS rows"; return WH_ERR_UNSUPPORTED; }
-    typedef void (*query_fn)(Prio3Dev, Workspace, uint8_t *, uint8_t *, int32_t *);
-    const query_fn qfn = polyeval ? k_query_polyeval
-                                  : (c->params.circuit == WH_HISTOGRAM ? k_query_psum<true> : k_query_psum<false>);
+    const QueryLaunch q = query_launch(c, false);
+    if (!q.fn) { c->err = "circuit has too many gadget calls for the query kernel's LDS rows"; return WH_ERR_UNSUPPORTED; }
     uint8_t *d_out = reinterpret_cast<uint8_t *>(c->d_out_shares);
     for (uint64_t base = 0; base < n; base += c->cap) {
         const uint32_t nb = (uint32_t)((n - base < c->cap) ? n - base : c->cap);
@@ -277,11 +291,108 @@ int32_t wh_prio3_prepare_batch_dev(wh_ctx *c, const uint8_t verify_key[16], cons
         hipLaunchKernelGGL(k_hash, dim3(2 * npad / 256), dim3(256), 0, c->stream, c->P, c->W, npad, vk0, vk1,
                            c->d_aes, d_ids + 16 * base, d_status + base); }
         { KTimer t_(c, WH_K_QUERY);
-        hipLaunchKernelGGL(qfn, dim3(polyeval ? (nb + 3) / 4 : nb), dim3(64 * qwaves), lds, c->stream, c->P, c->W,
+        hipLaunchKernelGGL(q.fn, dim3(q.polyeval ? (nb + 3) / 4 : nb), dim3(64 * q.waves), q.lds, c->stream, c->P, c->W,
                            tags_b, out_b, d_status + base); }
         HIPCHK(c, hipGetLastError());
     }
     return WH_OK;
+}
+
+int32_t wh_prio3_prepare_init_batch_dev(wh_ctx *c, const uint8_t verify_key[16], const uint8_t *d_blob,
+                                        const uint64_t *d_offsets, uint64_t n, uint8_t *d_prep, int32_t *d_status) {
+    if (!c || !verify_key || (n && (!d_blob || !d_offsets || !d_prep || !d_status))) return WH_ERR_PARAM;
+    if (n > 0xfffffff0ull) return WH_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    const HostSizes &z = c->z;
+    int32_t rc;
+    c->P.mode = 1;
+    if ((rc = alloc_workspace(c, pick_cap(c, n)))) return rc;
+    if ((rc = ensure(c, c->d_out_shares, c->out_cap, (n ? n : 1) * (uint64_t)z.output_len))) return rc;
+    if (n > c->cap) { c->err = "prepare_init keeps its state in the workspace: one sub-batch only"; return WH_ERR_UNSUPPORTED; }
+    uint64_t vk0, vk1;
+    memcpy(&vk0, verify_key, 8); memcpy(&vk1, verify_key + 8, 8);
+    c->n_last = n;
+    c->d_status_last = d_status;
+    const QueryLaunch q = query_launch(c, true);
+    if (!q.fn) { c->err = "circuit has too many gadget calls for the query kernel's LDS rows"; return WH_ERR_UNSUPPORTED; }
+    if (!n) return WH_OK;
+    const uint32_t nb = (uint32_t)n, npad = (nb + 255) / 256 * 256;
+    uint8_t *d_out = reinterpret_cast<uint8_t *>(c->d_out_shares);
+    HIPCHK(c, hipMemsetAsync(c->W.counters, 0, 64, c->stream));
+    { KTimer t_(c, WH_K_PARSE);
+    hipLaunchKernelGGL(k_parse_base, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, d_blob, d_offsets, nb, d_status,
+                       d_prep, d_out); }
+    { KTimer t_(c, WH_K_EXPAND);
+    launch_expand(c->P, c->W, npad, c->stream); }
+    { KTimer t_(c, WH_K_HASH);
+    hipLaunchKernelGGL(k_hash_base, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, vk0, vk1, d_status); }
+    { KTimer t_(c, WH_K_QUERY);
+    hipLaunchKernelGGL(q.fn, dim3(q.polyeval ? (nb + 3) / 4 : nb), dim3(64 * q.waves), q.lds, c->stream, c->P, c->W, d_prep,
+                       d_out, d_status); }
+    HIPCHK(c, hipGetLastError());
+    return WH_OK;
+}
+
+int32_t wh_prio3_prepare_init_batch(wh_ctx *c, const uint8_t verify_key[16], const uint8_t *blob, const uint64_t *offsets,
+                                    uint64_t n, uint8_t *prep_shares, int32_t *status) {
+    if (!c || !verify_key || (n && (!blob || !offsets || !prep_shares || !status))) return WH_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n == 0) { c->n_last = 0; return WH_OK; }
+    for (uint64_t i = 0; i < n; i++) if (offsets[i + 1] < offsets[i]) return WH_ERR_PARAM;
+    int32_t rc;
+    const uint64_t base0 = offsets[0], bytes = offsets[n] - base0, prep_bytes = 16ull * (c->z.verifier_len + 1) * n;
+    if ((rc = ensure(c, c->d_blob, c->blob_cap, bytes + 64))) return rc;
+    if ((rc = ensure(c, c->d_offsets, c->off_cap, n + 1))) return rc;
+    if ((rc = ensure(c, c->d_prep, c->prep_cap, prep_bytes))) return rc;
+    if ((rc = ensure(c, c->d_status_own, c->status_cap, n))) return rc;
+    std::vector<uint64_t> rel(n + 1);
+    for (uint64_t i = 0; i <= n; i++) rel[i] = offsets[i] - base0;
+    HIPCHK(c, hipMemcpyAsync(c->d_blob, blob + base0, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_offsets, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((rc = wh_prio3_prepare_init_batch_dev(c, verify_key, c->d_blob, c->d_offsets, n, c->d_prep, c->d_status_own))) return rc;
+    HIPCHK(c, hipMemcpyAsync(prep_shares, c->d_prep, prep_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(status, c->d_status_own, 4 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return WH_OK;
+}
+
+int32_t wh_prio3_prepare_finish_batch(wh_ctx *c, const uint8_t *const *prep_shares, uint64_t n, uint8_t *prep_msgs,
+                                      int32_t *status) {
+    if (!c || (n && (!prep_shares || !prep_msgs || !status))) return WH_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n != c->n_last || c->P.mode != 1 || (n && c->d_status_last != c->d_status_own)) return WH_ERR_STATE;
+    if (n == 0) return WH_OK;
+    const uint32_t na = c->params.num_aggregators;
+    const uint64_t prep_bytes = 16ull * (c->z.verifier_len + 1) * n;
+    int32_t rc;
+    uint8_t *d_all = nullptr, *d_msgs = nullptr;
+    const uint8_t **d_ptrs = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_all, prep_bytes * na));
+    HIPCHK(c, hipMalloc((void **)&d_msgs, 16 * n));
+    HIPCHK(c, hipMalloc((void **)&d_ptrs, sizeof(uint8_t *) * na));
+    std::vector<const uint8_t *> ptrs(na);
+    rc = WH_OK;
+    hipError_t e = hipSuccess;
+    for (uint32_t a = 0; a < na && e == hipSuccess; a++) {
+        if (!prep_shares[a]) { rc = WH_ERR_PARAM; break; }
+        ptrs[a] = d_all + prep_bytes * a;
+        e = hipMemcpyAsync(d_all + prep_bytes * a, prep_shares[a], prep_bytes, hipMemcpyHostToDevice, c->stream);
+    }
+    if (!rc && e == hipSuccess) e = hipMemcpyAsync(d_ptrs, ptrs.data(), sizeof(uint8_t *) * na, hipMemcpyHostToDevice, c->stream);
+    if (!rc && e == hipSuccess) e = hipMemsetAsync(d_msgs, 0, 16 * n, c->stream);
+    if (!rc && e == hipSuccess) {
+        hipLaunchKernelGGL(k_finish_base, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, c->stream, c->P, c->W, d_ptrs, (uint32_t)n,
+                           d_msgs, c->d_status_own);
+        e = hipGetLastError();
+    }
+    if (!rc && e == hipSuccess) e = hipMemcpyAsync(prep_msgs, d_msgs, 16 * n, hipMemcpyDeviceToHost, c->stream);
+    if (!rc && e == hipSuccess) e = hipMemcpyAsync(status, c->d_status_own, 4 * n, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e2 = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = e2;
+    hipFree(d_all); hipFree(d_msgs); hipFree(d_ptrs);
+    if (!rc && e != hipSuccess) { c->err = hipGetErrorString(e); rc = WH_ERR_HIP; }
+    return rc;
 }
 
 int32_t wh_prio3_prepare_batch(wh_ctx *c, const uint8_t verify_key[16], const uint8_t *blob, const uint64_t *offsets,

@@ -160,6 +160,7 @@ extern "C" int32_t wh_client_shard_batched(const wh_prio3_params *params, const 
                                            uint8_t *helper_report) {
     Flp flp;
     flp.p = *params;
+    if (flp.p.num_aggregators != 2) return WH_ERR_PARAM;    // the batched protocol is Alice and Bob
     int32_t rc = host_sizes(flp.p, flp.z);
     if (rc) return rc;
     const HostSizes &z = flp.z;
@@ -224,6 +225,7 @@ extern "C" int32_t wh_client_shard_many(const wh_prio3_params *params, const uin
                                         const uint8_t *nonces, const uint8_t *rands, uint64_t first_client_id, uint64_t n,
                                         uint32_t nthreads, uint8_t *leader_reports, uint8_t *helper_reports) {
     HostSizes z;
+    if (params->num_aggregators != 2) return WH_ERR_PARAM;
     int32_t rc = host_sizes(*params, z);
     if (rc) return rc;
     if (nthreads < 1) nthreads = 1;

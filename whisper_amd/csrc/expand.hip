@@ -17,15 +17,16 @@ __global__ void __launch_bounds__(256) k_expand(Prio3Dev P, Workspace W, uint32_
     uint32_t slot = which ? job - npad : job;
     if (slot >= nh) return;
     const RepDesc d = W.desc[W.hlist[slot]];
-    const uint8_t *seeds = d.base + 49;  // meas_seed | proof1_seed | jr_blind | proof2_seed
+    // batched report: meas_seed | proof1_seed | jr_blind | proof2_seed; VdafKey: meas_seed | proof_seed | blind
+    const uint8_t *seeds = d.seeds;
     Sponge s;
-    const uint32_t nst = which ? 2 : 1;
+    const uint32_t nst = which ? (P.mode ? 1 : 2) : 1;
 #pragma unroll 1
     for (uint32_t t = 0; t < nst; t++) {
         const uint8_t *seed = which ? seeds + (t ? 48 : 16) : seeds;
-        uint8_t *out = const_cast<uint8_t *>(which ? (t ? d.proof2 : d.proof1) : d.meas);
+        uint8_t *out = const_cast<uint8_t *>(which ? ((t || P.mode) ? d.proof2 : d.proof1) : d.meas);
         s.init_xof(P.alg_id, which ? DST_PROOF : DST_MEAS, seed);
-        s.absorb3(d.base + 48, 1, nullptr, 0, nullptr, 0);   // binder = [agg_id]
+        s.absorb3(P.mode ? d.base : d.base + 48, 1, nullptr, 0, nullptr, 0);   // binder = [agg_id]
         s.finalize();
         xof_emit(s, out, which ? P.proof_len : P.input_len, P.sampler_bound);
     }

@@ -19,7 +19,7 @@ struct HostSizes {
 };
 
 inline int32_t host_sizes(const wh_prio3_params &p, HostSizes &s) {
-    if (p.num_aggregators != 2) return WH_ERR_PARAM;
+    if (p.num_aggregators < 2 || p.num_aggregators > 255) return WH_ERR_PARAM;
     switch (p.circuit) {
     case WH_SUMVEC:
         if (!p.bits || !p.len || !p.chunk || p.bits > 127 || (uint64_t)p.bits * p.len > (1u << 24)) return WH_ERR_PARAM;
@@ -37,6 +37,7 @@ inline int32_t host_sizes(const wh_prio3_params &p, HostSizes &s) {
         break;
     default: return WH_ERR_PARAM;
     }
+    if (p.alg_id) s.alg_id = p.alg_id;
     s.m = next_pow2_u32(1 + s.calls);
     s.log2m = log2_u32(s.m);
     if (s.log2m + 1 > 20) return WH_ERR_PARAM;  // fft.rs:42-44 MAX_ROOTS

@@ -82,7 +82,7 @@ __global__ void k_parse(Prio3Dev P, Workspace W, const uint8_t *blob, const uint
     const uint8_t *rep = blob + offsets[i];
     uint64_t rep_len = offsets[i + 1] - offsets[i];
     RepDesc d;
-    d.base = rep; d.meas = d.proof1 = d.proof2 = d.tail = d.jr_blind = nullptr; d.role = 0; d.hslot = 0;
+    d.base = rep; d.meas = d.proof1 = d.proof2 = d.tail = d.jr_blind = d.seeds = nullptr; d.role = 0; d.hslot = 0;
     int32_t st = ST_OK;
     if (rep_len < 49) st = ST_ERR_SHORT;
     if (!st) {
@@ -118,6 +118,7 @@ __global__ void k_parse(Prio3Dev P, Workspace W, const uint8_t *blob, const uint
             d.proof1 = row + 16ull * P.input_len;
             d.proof2 = d.proof1 + 16ull * P.proof_len;
             d.jr_blind = rep + 49 + 32;
+            d.seeds = rep + 49;
         }
     }
     // the later kernels run per role over the two lists; a malformed report is in neither and
@@ -134,6 +135,64 @@ __global__ void k_parse(Prio3Dev P, Workspace W, const uint8_t *blob, const uint
 
 // (the Helper expansion kernel lives in expand.hip: hipcc 7.2 crashes in its inliner when this
 // translation unit holds both sponge kernels)
+
+// Per-report constants of the query kernels, computed by the lane that derived the randomness:
+// barycentric weights L_j(r) = (r^m - 1)/m * w^j / (r - w^j), j = 0..calls, w = omega_m (one
+// inversion per report: prefix products of (r - w^j) are parked in the weight row), and for the
+// ParallelSum circuits the weights as limbs and small power tables of rho and r.
+__device__ __forceinline__ void weights_and_tables(const Prio3Dev &P, const Workspace &W, uint32_t i, const F128 &r,
+                                                   const F128 &rm, const F128 &rho) {
+    // Barycentric weights for run 2 (run 1's verifier never reaches the tag, prio3.rs:2713):
+    //   L_j(r) = (r^m - 1)/m * w^j / (r - w^j),  j = 0..calls,  w = omega_m.
+    // One inversion per report: prefix products of (r - w^j) are parked in the weight row.
+    F128 *L = W.weights + (uint64_t)i * P.n_weights;
+    F128 acc = f_one();
+    for (uint32_t j = 0; j < P.n_weights; j++) {
+        L[j] = acc;
+        acc = f_mul(acc, f_sub(r, P.omega[j]));
+    }
+    F128 inv = f_inv(acc);
+    F128 k = f_mul(f_sub(rm, f_one()), P.m_inv);
+    for (uint32_t j = P.n_weights; j-- > 0;) {
+        F128 w = P.omega[j];
+        F128 dinv = f_mul(inv, L[j]);          // 1 / (r - w^j)
+        inv = f_mul(inv, f_sub(r, w));
+        L[j] = f_mul(f_mul(k, w), dinv);
+    }
+    if (P.circuit != CIRCUIT_AVERAGE) {
+        // what the query kernel would otherwise compute with a whole wavefront per value:
+        // small power tables of rho and r, and the weights as limbs with
+        // M_j = L_j rho^(chunk (j-1)) next to L_j
+        RepPow *pw = &W.pows[i];
+        F128 t = rho;
+        for (int q = 0; q < 8; q++) { pw->rho_lo[q] = t; if (q < 7) t = f_mul(t, rho); }
+        F128 u = f_one();
+        for (int q = 0; q < 8; q++) { pw->rho_hi[q] = u; u = f_mul(u, t); }     // t = rho^8
+        const F128 u2 = f_sqr(u);                                               // u = rho^64
+        pw->rho64[0] = f_one(); pw->rho64[1] = u; pw->rho64[2] = u2; pw->rho64[3] = f_mul(u2, u); pw->rho64[4] = f_sqr(u2);
+        t = f_one();
+        for (int q = 0; q < 8; q++) { pw->r_lo[q] = t; t = f_mul(t, r); }
+        u = f_one();
+        for (int q = 0; q < 8; q++) { pw->r_hi[q] = u; u = f_mul(u, t); }       // t = r^8
+        pw->r64 = u;
+        const F128 rc = f_pow_u32(rho, P.chunk);
+        uint4 *wl = reinterpret_cast<uint4 *>(W.wlimbs + (uint64_t)i * 12 * P.calls);
+        F128 pj = f_one(), sumL = f_zero();
+        for (uint32_t j = 1; j <= P.calls; j++) {
+            const F128 l = L[j], m = f_mul(l, pj);
+            sumL = f_add(sumL, l);
+            uint32_t tl[5], tm[5];
+            f_split26(l, tl);
+            f_split26(m, tm);
+            wl[3 * (j - 1)] = make_uint4(tl[0], tl[1], tl[2], tl[3]);
+            wl[3 * (j - 1) + 1] = make_uint4(tl[4], tm[0], tm[1], tm[2]);
+            wl[3 * (j - 1) + 2] = make_uint4(tm[3], tm[4], 0, 0);
+            pj = f_mul(pj, rc);
+        }
+        pw->L0 = L[0];
+        pw->h_sumL = f_mul(P.half, sumL);
+    }
+}
 
 // ---------------------------------------------------------------------------------- hash ----
 // Job A (lanes [0, npad)): six sponges -- own joint-rand part (prio3.rs:2543-2555), joint-rand
@@ -217,57 +276,7 @@ __global__ void __launch_bounds__(256) k_hash(Prio3Dev P, Workspace W, uint32_t 
         F128 r1 = sc->qr[0], r = sc->qr[1];
         F128 r1m = f_sqr_n(r1, P.log2m), rm = f_sqr_n(r, P.log2m);
         if (f_eq(r1m, f_one()) || f_eq(rm, f_one())) { status[i] = ST_ERR_QUERY_RAND; return; }
-        // Barycentric weights for run 2 (run 1's verifier never reaches the tag, prio3.rs:2713):
-        //   L_j(r) = (r^m - 1)/m * w^j / (r - w^j),  j = 0..calls,  w = omega_m.
-        // One inversion per report: prefix products of (r - w^j) are parked in the weight row.
-        F128 *L = W.weights + (uint64_t)i * P.n_weights;
-        F128 acc = f_one();
-        for (uint32_t j = 0; j < P.n_weights; j++) {
-            L[j] = acc;
-            acc = f_mul(acc, f_sub(r, P.omega[j]));
-        }
-        F128 inv = f_inv(acc);
-        F128 k = f_mul(f_sub(rm, f_one()), P.m_inv);
-        for (uint32_t j = P.n_weights; j-- > 0;) {
-            F128 w = P.omega[j];
-            F128 dinv = f_mul(inv, L[j]);          // 1 / (r - w^j)
-            inv = f_mul(inv, f_sub(r, w));
-            L[j] = f_mul(f_mul(k, w), dinv);
-        }
-        if (P.circuit != CIRCUIT_AVERAGE) {
-            // what the query kernel would otherwise compute with a whole wavefront per value:
-            // small power tables of rho and r, and the weights as limbs with
-            // M_j = L_j rho^(chunk (j-1)) next to L_j
-            RepPow *pw = &W.pows[i];
-            const F128 rho = sc->jr[P.jr_len];      // run 2's joint_rand[0]
-            F128 t = rho;
-            for (int q = 0; q < 8; q++) { pw->rho_lo[q] = t; if (q < 7) t = f_mul(t, rho); }
-            F128 u = f_one();
-            for (int q = 0; q < 8; q++) { pw->rho_hi[q] = u; u = f_mul(u, t); }     // t = rho^8
-            const F128 u2 = f_sqr(u);                                               // u = rho^64
-            pw->rho64[0] = f_one(); pw->rho64[1] = u; pw->rho64[2] = u2; pw->rho64[3] = f_mul(u2, u); pw->rho64[4] = f_sqr(u2);
-            t = f_one();
-            for (int q = 0; q < 8; q++) { pw->r_lo[q] = t; t = f_mul(t, r); }
-            u = f_one();
-            for (int q = 0; q < 8; q++) { pw->r_hi[q] = u; u = f_mul(u, t); }       // t = r^8
-            pw->r64 = u;
-            const F128 rc = f_pow_u32(rho, P.chunk);
-            uint4 *wl = reinterpret_cast<uint4 *>(W.wlimbs + (uint64_t)i * 12 * P.calls);
-            F128 pj = f_one(), sumL = f_zero();
-            for (uint32_t j = 1; j <= P.calls; j++) {
-                const F128 l = L[j], m = f_mul(l, pj);
-                sumL = f_add(sumL, l);
-                uint32_t tl[5], tm[5];
-                f_split26(l, tl);
-                f_split26(m, tm);
-                wl[3 * (j - 1)] = make_uint4(tl[0], tl[1], tl[2], tl[3]);
-                wl[3 * (j - 1) + 1] = make_uint4(tl[4], tm[0], tm[1], tm[2]);
-                wl[3 * (j - 1) + 2] = make_uint4(tm[3], tm[4], 0, 0);
-                pj = f_mul(pj, rc);
-            }
-            pw->L0 = L[0];
-            pw->h_sumL = f_mul(P.half, sumL);
-        }
+        weights_and_tables(P, W, i, r, rm, sc->jr[P.jr_len]);
     } else {
         // testing id: AES128_vk(client_id.to_le_bytes()) (main.rs:51, common/src/prg.rs:650-655)
         const uint8_t *sbox = aes_rk + 176;
@@ -297,6 +306,163 @@ __global__ void __launch_bounds__(256) k_hash(Prio3Dev P, Workspace W, uint32_t 
         }
 #pragma unroll
         for (int b = 0; b < 16; b++) testing_ids[16ull * i + b] = st[b];
+    }
+}
+
+// ------------------------------------------------- draft-07 prepare_init: parse and hash ----
+// VdafKey::decode_with_param (vdaf.rs:219-233) as far as structure goes:
+//   agg_id u8 | public share: num_aggregators joint-rand parts | input share | nonce[16]
+// input share (prio3.rs:1745-1759): Leader  meas[input_len] | proof[proof_len] | blind[16]
+//                                   Helper  meas_seed[16] | proof_seed[16] | blind[16]
+__global__ void k_parse_base(Prio3Dev P, Workspace W, const uint8_t *blob, const uint64_t *offsets, uint32_t n,
+                             int32_t *status, uint8_t *prep_shares, uint8_t *out_shares) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *rep = blob + offsets[i];
+    uint64_t rep_len = offsets[i + 1] - offsets[i];
+    RepDesc d;
+    d.base = rep; d.meas = d.proof1 = d.proof2 = d.tail = d.jr_blind = d.seeds = nullptr; d.role = 0; d.hslot = 0;
+    int32_t st = ST_OK;
+    if (rep_len < 1) st = ST_ERR_SHORT;
+    if (!st) {
+        d.role = rep[0];
+        if (d.role >= P.num_aggregators) st = ST_ERR_AGG_ID;
+    }
+    if (!st) {
+        const uint64_t head = 1 + 16ull * P.num_aggregators;
+        const uint64_t share_len = d.role == 0 ? 16ull * (P.input_len + P.proof_len) + 16 : 48;
+        if (rep_len < head + share_len + 16) st = ST_ERR_SHORT;
+        if (!st) {
+            d.tail = rep + head + share_len;            // nonce
+            if (d.role == 0) {
+                d.meas = rep + head;
+                d.proof2 = d.meas + 16ull * P.input_len;
+                d.jr_blind = d.proof2 + 16ull * P.proof_len;
+                W.llist[atomicAdd(&W.counters[1], 1u)] = i;
+            } else {
+                d.hslot = atomicAdd(&W.counters[0], 1u);
+                W.hlist[d.hslot] = i;
+                uint8_t *row = W.hrows + (uint64_t)d.hslot * W.hrow_bytes;
+                d.meas = row;
+                d.proof2 = row + 16ull * P.input_len;
+                d.seeds = rep + head;
+                d.jr_blind = rep + head + 32;
+            }
+        }
+    }
+    if (st) {
+        F128 *out_row = reinterpret_cast<F128 *>(out_shares) + (uint64_t)i * P.output_len;
+        for (uint32_t e = 0; e < P.output_len; e++) out_row[e] = f_zero();
+        F128 *prep = reinterpret_cast<F128 *>(prep_shares) + (uint64_t)i * (P.verifier_len + 1);
+        for (uint32_t e = 0; e <= P.verifier_len; e++) prep[e] = f_zero();
+    }
+    W.desc[i] = d;
+    status[i] = st;
+}
+
+// Prio3::prepare_init up to the query (prio3.rs:2232-2300): query randomness XOF(verify_key, 5) .
+// nonce; own joint-rand part XOF(blind, 7) . [agg_id] . nonce . enc(meas); joint-rand seed over
+// the public share's parts with the own part substituted (:482-493); joint randomness XOF(seed, 3).
+// The joint randomness goes where the batched path keeps run 2's, so the query kernels read it
+// the same way; the seed is kept for prepare_next's check (:2407-2424).
+__global__ void __launch_bounds__(256) k_hash_base(Prio3Dev P, Workspace W, uint64_t vk0, uint64_t vk1, int32_t *status) {
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i;
+    if (!report_of_slot(W, slot, i) || status[i] != ST_OK) return;
+    const RepDesc d = W.desc[i];
+    RepScal *sc = &W.scal[i];
+    const uint8_t *parts = d.base + 1, *nonce = d.tail;
+    uint8_t *own = reinterpret_cast<uint8_t *>(&sc->own);
+    Sponge s;
+    F128 sd = f_zero();
+#pragma unroll 1
+    for (uint32_t stg = 0; stg < 4; stg++) {
+        uint32_t usage = 0, l1 = 0, l2 = 0, l3 = 0, emit_n = 0;
+        uint64_t k0 = 0, k1 = 0;
+        const uint8_t *p1 = nullptr, *p2 = nullptr, *p3 = nullptr;
+        uint8_t *emit_p = nullptr;
+        switch (__builtin_amdgcn_readfirstlane(stg)) {
+        case 0:
+            usage = DST_JR_PART; k0 = ld64(d.jr_blind); k1 = ld64(d.jr_blind + 8);
+            p1 = d.base; l1 = 1; p2 = nonce; l2 = 16; p3 = d.meas; l3 = 16u * P.input_len;
+            break;
+        case 1:
+            usage = DST_JR_SEED;
+            p1 = parts; l1 = 16 * d.role; p2 = own; l2 = 16;
+            p3 = parts + 16 * (d.role + 1); l3 = 16 * (P.num_aggregators - 1 - d.role);
+            break;
+        case 2:
+            usage = DST_JOINT_RAND; k0 = sd.lo; k1 = sd.hi; emit_n = P.jr_len;
+            emit_p = reinterpret_cast<uint8_t *>(sc->jr + P.jr_len);
+            break;
+        default:
+            usage = DST_QUERY_RAND; k0 = vk0; k1 = vk1; p1 = nonce; l1 = 16; emit_n = 1;
+            emit_p = reinterpret_cast<uint8_t *>(sc->qr + 1);
+            break;
+        }
+        s.init_xof(P.alg_id, usage, k0, k1);
+        s.absorb3(p1, l1, p2, l2, p3, l3);
+        s.finalize();
+        if (emit_n) {
+            xof_emit(s, emit_p, emit_n, P.sampler_bound);
+        } else {
+            sd = F128{s.st[0], s.st[1]};
+            if (stg == 0) st128(own, sd);
+            else sc->hash = sd;                     // the joint-rand seed
+        }
+    }
+    const F128 r = sc->qr[1];
+    const F128 rm = f_sqr_n(r, P.log2m);
+    if (f_eq(rm, f_one())) { status[i] = ST_ERR_QUERY_RAND; return; }      // flp.rs:413-419
+    weights_and_tables(P, W, i, r, rm, sc->jr[P.jr_len]);
+}
+
+// prepare_shares_to_prepare_message + prepare_next (prio3.rs:2347-2442) for a batch: sum the
+// aggregators' verifier shares, decide (flp.rs:483-512), derive the joint-rand seed from the
+// parts in the prepare shares and compare it with the one prepare_init used.  One wavefront per
+// report.  shares[a] points at aggregator a's n prepare shares ((verifier_len + 1) elements each).
+__global__ void __launch_bounds__(256) k_finish_base(Prio3Dev P, Workspace W, const uint8_t *const *shares, uint32_t n,
+                                                     uint8_t *prep_msgs, int32_t *status) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t i = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (i >= n || status[i] != ST_OK) return;
+    const uint32_t vl = P.verifier_len, na = P.num_aggregators;
+    const uint64_t row = 16ull * (vl + 1) * i;
+    auto ver = [&](uint32_t e, uint32_t &bad) -> F128 {        // sum of the shares' element e
+        F128 acc = f_zero();
+        for (uint32_t a = 0; a < na; a++) {
+            F128 v = ld128g(shares[a] + row + 16ull * e);
+            bad |= !f_in_range(v.lo, v.hi);
+            acc = f_add(acc, v);
+        }
+        return acc;
+    };
+    uint32_t bad = 0;
+    bool ok;
+    if (P.circuit == CIRCUIT_AVERAGE) {
+        F128 a = ver(0, bad), b = ver(1, bad), c = ver(2, bad);
+        ok = f_is_zero(a) && f_eq(f_sub(f_sqr(b), b), c);
+    } else {
+        F128 acc = f_zero();
+        for (uint32_t k = lane; k < P.chunk; k += 64) acc = f_add(acc, f_mul(ver(1 + 2 * k, bad), ver(2 + 2 * k, bad)));
+        acc = wave_sum(acc);
+        F128 first = ver(0, bad), last = ver(1 + P.arity, bad);
+        ok = f_is_zero(first) && f_eq(acc, last);
+    }
+    bad = wave_or(bad);
+    if (lane == 0) {
+        // joint-rand seed over the parts the aggregators sent (prio3.rs:2380-2389)
+        Sponge s;
+        s.init_xof(P.alg_id, DST_JR_SEED, 0ull, 0ull);
+        for (uint32_t a = 0; a < na; a++) s.absorb_f(ld128(shares[a] + row + 16ull * vl));
+        s.finalize();
+        const F128 seed = F128{s.st[0], s.st[1]};
+        st128(prep_msgs + 16ull * i, seed);
+        int32_t st = ST_OK;
+        if (bad) st = ST_ERR_MODULUS;
+        else if (!ok) st = ST_ERR_DECIDE;
+        else if (!f_eq(seed, W.scal[i].hash)) st = ST_ERR_JOINT_RAND;
+        status[i] = st;
     }
 }
 
@@ -352,7 +518,9 @@ struct QueryShared {      // behind the weight rows in LDS
     uint32_t bad[4];
 };
 
-template <bool HIST>
+// BASE: draft-07 prepare_init -- the verifier share itself is the output (`tags` then points at
+// the prepare shares, (verifier_len + 1) elements per report: verifier | own joint-rand part).
+template <bool HIST, bool BASE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_query_psum(Prio3Dev P, Workspace W, uint8_t *tags,
                                                     uint8_t *out_shares, int32_t *status) {
     extern __shared__ uint32_t lds_w[];
@@ -360,10 +528,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     uint32_t i;
     if (!report_of_slot(W, blockIdx.x, i)) return;
     uint8_t *tag_out = tags + 16ull * i;
+    F128 *ver_row = reinterpret_cast<F128 *>(tags) + (uint64_t)i * (P.verifier_len + 1);    // BASE
     F128 *out_row = reinterpret_cast<F128 *>(out_shares) + (uint64_t)i * P.output_len;
     if (status[i] != ST_OK) {               // uniform over the workgroup
         for (uint32_t e = threadIdx.x; e < P.output_len; e += blockDim.x) out_row[e] = f_zero();
-        if (threadIdx.x == 0) st128(tag_out, f_zero());
+        if (BASE) for (uint32_t e = threadIdx.x; e <= P.verifier_len; e += blockDim.x) ver_row[e] = f_zero();
+        else if (threadIdx.x == 0) st128(tag_out, f_zero());
         return;
     }
     const uint32_t calls = P.calls;
@@ -483,10 +653,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
             bad |= !f_in_range(s_even.lo, s_even.hi) | !f_in_range(s_odd.lo, s_odd.hi);
             F128 v_even = f_add(f_mul(L0, s_even), f_mul(rk, A));
             F128 v_odd = f_sub(f_add(f_mul(L0, s_odd), B), h_sumL);
-            F128 q_even = ld128g(pp1 + 16ull * (1 + 2 * k)), q_odd = ld128g(pp1 + 16ull * (2 + 2 * k));
-            bad |= !f_in_range(q_even.lo, q_even.hi) | !f_in_range(q_odd.lo, q_odd.hi);
-            if (leader) { v_even = f_sub(v_even, q_even); v_odd = f_sub(v_odd, q_odd); }
-            tag = f_add(tag, f_add(f_mul(rlc[1 + 2 * k], v_even), f_mul(rlc[2 + 2 * k], v_odd)));
+            if (BASE) {
+                ver_row[1 + 2 * k] = v_even;
+                ver_row[2 + 2 * k] = v_odd;
+            } else {
+                F128 q_even = ld128g(pp1 + 16ull * (1 + 2 * k)), q_odd = ld128g(pp1 + 16ull * (2 + 2 * k));
+                bad |= !f_in_range(q_even.lo, q_even.hi) | !f_in_range(q_odd.lo, q_odd.hi);
+                if (leader) { v_even = f_sub(v_even, q_even); v_odd = f_sub(v_odd, q_odd); }
+                tag = f_add(tag, f_add(f_mul(rlc[1 + 2 * k], v_even), f_mul(rlc[2 + 2 * k], v_odd)));
+            }
         }
         if (kb + 64 * S < P.chunk) rho_kb = f_mul(rho_kb, pw->rho64[S]);
     }
@@ -537,7 +712,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     // last wave: decide on the two public proofs (prio3.rs:2762-2786): pp[0] == 0 and
     // sum_k pp[1+2k] pp[2+2k] == pp[1+arity]; Leader only: the proof share of run 1 is hashed,
     // never evaluated, but it still has to decode
-    if (wave == S - 1) {
+    if (!BASE && wave == S - 1) {
         if (leader)
             for (uint32_t e = lane; e < P.proof_len; e += 64) {
                 F128 v = ld128g(d.proof1 + 16ull * e);
@@ -571,8 +746,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     __syncthreads();
     bad = 0;
     for (uint32_t w = 0; w < S; w++) bad |= sh->bad[w];
-    if (bad)
+    if (bad) {
         for (uint32_t e = threadIdx.x; e < P.output_len; e += blockDim.x) out_row[e] = f_zero();
+        if (BASE) for (uint32_t e = threadIdx.x; e <= P.verifier_len; e += blockDim.x) ver_row[e] = f_zero();
+    }
     if (threadIdx.x == 0) {
         const uint32_t vl = P.verifier_len;
         tag = f_zero();
@@ -582,6 +759,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
             // types.rs:428-436: rho' * range_check + rho'^2 * (sum x - h)
             F128 rho2 = sc->jr[P.jr_len + 1];
             v0 = f_add(f_mul(rho2, v0), f_mul(f_sqr(rho2), f_sub(sx, P.half)));
+        }
+        if (BASE) {
+            // Prio3PrepareShare (prio3.rs:1953-1970): verifier share | joint-rand part
+            if (bad) status[i] = ST_ERR_MODULUS;
+            else { ver_row[0] = v0; ver_row[1 + P.arity] = g_at_r; ver_row[vl] = sc->own; }
+            return;
         }
         F128 q0 = ld128g(pp1), qg = ld128g(pp1 + 16ull * (1 + P.arity));
         F128 d0 = leader ? f_sub(v0, q0) : v0;
@@ -608,6 +791,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 //   v[1] = L_0 proof[0] + sum_j L_j x_{j-1}    -- the single wire polynomial at r
 //   v[2] = G(r)
 // decide on a public proof: pp[0] == 0 and pp[1]^2 - pp[1] == pp[2].
+template <bool BASE>
 __global__ void __launch_bounds__(256) k_query_polyeval(Prio3Dev P, Workspace W, uint8_t *tags,
                                                         uint8_t *out_shares, int32_t *status) {
     extern __shared__ F128 lds[];
@@ -616,9 +800,14 @@ __global__ void __launch_bounds__(256) k_query_polyeval(Prio3Dev P, Workspace W,
     uint32_t i;
     if (!report_of_slot(W, slot, i)) return;
     uint8_t *tag_out = tags + 16ull * i;
+    F128 *ver_row = reinterpret_cast<F128 *>(tags) + (uint64_t)i * 4;     // BASE: verifier[3] | joint-rand part
     F128 *out_row = reinterpret_cast<F128 *>(out_shares) + (uint64_t)i;   // output_len == 1
     if (status[i] != ST_OK) {
-        if (lane == 0) { out_row[0] = f_zero(); st128(tag_out, f_zero()); }
+        if (lane == 0) {
+            out_row[0] = f_zero();
+            if (BASE) { for (int e = 0; e < 4; e++) ver_row[e] = f_zero(); }
+            else st128(tag_out, f_zero());
+        }
         return;
     }
     const uint32_t m = P.m;
@@ -632,7 +821,7 @@ __global__ void __launch_bounds__(256) k_query_polyeval(Prio3Dev P, Workspace W,
     const bool leader = d.role == 0;
     uint32_t bad = 0;
 
-    if (leader)
+    if (!BASE && leader)
         for (uint32_t e = lane; e < P.proof_len; e += 64) {
             F128 v = ld128(d.proof1 + 16ull * e);
             bad |= !f_in_range(v.lo, v.hi);
@@ -690,6 +879,16 @@ __global__ void __launch_bounds__(256) k_query_polyeval(Prio3Dev P, Workspace W,
     out = wave_sum(out);
 
     F128 tag = f_zero();
+    if (BASE) {
+        bad = wave_or(bad);
+        if (lane == 0) {
+            if (bad) { status[i] = ST_ERR_MODULUS; out = f_zero(); v0 = v1 = g_at_r = f_zero(); }
+            out_row[0] = out;
+            ver_row[0] = v0; ver_row[1] = v1; ver_row[2] = g_at_r;
+            ver_row[3] = bad ? f_zero() : sc->own;
+        }
+        return;
+    }
     if (lane == 0) {
         F128 ver[3] = {v0, v1, g_at_r};
         F128 dec[2];

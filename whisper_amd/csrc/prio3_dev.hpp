@@ -12,7 +12,7 @@ enum : uint32_t { CIRCUIT_SUMVEC = 0, CIRCUIT_HISTOGRAM = 1, CIRCUIT_AVERAGE = 2
 // status codes (include/whisper_gfx950.h)
 enum : int32_t {
     ST_OK = 0, ST_ERR_PARAM = -1, ST_ERR_SHORT = -2, ST_ERR_MODULUS = -3, ST_ERR_AGG_ID = -4,
-    ST_ERR_NUM_QUERIES = -5, ST_ERR_QUERY_RAND = -6
+    ST_ERR_NUM_QUERIES = -5, ST_ERR_QUERY_RAND = -6, ST_ERR_DECIDE = -7, ST_ERR_JOINT_RAND = -8
 };
 
 // Prio3 usage constants (vdaf/prio3.rs:69-78)
@@ -28,6 +28,8 @@ struct Prio3Dev {
     uint32_t alg_id;
     uint32_t leader_len, helper_len;  // encoded report sizes
     uint32_t n_weights;               // calls + 1
+    uint32_t num_aggregators;
+    uint32_t mode;                    // 0: whisper's batched reports; 1: draft-07 VdafKey (prepare_init)
     F128 half;                        // num_shares^-1 = 2^-1
     F128 m_inv;                       // m^-1
     F128 sampler_bound;               // p (test hook: a smaller bound makes the sampler's skip branch run)
@@ -43,6 +45,7 @@ struct RepDesc {
     const uint8_t *proof2;  // proof_len elements, run 2
     const uint8_t *tail;    // public_share_second | num_queries | pp0 | pp1 | qr_blind | nonce
     const uint8_t *jr_blind;
+    const uint8_t *seeds;   // Helper: measurement-share seed; the proof-share seeds follow at P.mode's offsets
     uint32_t role;          // agg_id
     uint32_t hslot;         // helper slot in the expansion rows
 };

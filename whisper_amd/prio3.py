@@ -18,8 +18,8 @@ AVG_BITS = 64  # bin-utils/src/lib.rs:34
 
 
 class Prio3Params:
-    def __init__(self, circuit, bits=0, length=0, chunk=0, num_aggregators=2):
-        self.c = Params(circuit, bits, length, chunk, num_aggregators, 0)
+    def __init__(self, circuit, bits=0, length=0, chunk=0, num_aggregators=2, alg_id=0):
+        self.c = Params(circuit, bits, length, chunk, num_aggregators, alg_id)
         s = Sizes()
         rc = lib.wh_prio3_sizes_of(C.byref(self.c), C.byref(s))
         if rc:
@@ -125,6 +125,42 @@ class Prio3:
                                              tags.ctypes.data, ids.ctypes.data, status.ctypes.data), "prepare_batch")
         self.n_last = n
         return tags, ids, status
+
+    # ---- un-batched Prio3 (draft-07): server-base-prio3/src/main.rs:26-103 ----
+    @staticmethod
+    def encode_vdaf_key(agg_id, public_share, input_share, nonce):
+        """VdafKey::encode (vdaf.rs:210-217)."""
+        return bytes([agg_id]) + bytes(public_share) + bytes(input_share) + bytes(nonce)
+
+    def prepare_init_encoded_keys(self, verify_key, keys):
+        """The first map of run_vdaf_prepare: decode + Prio3::prepare_init per VdafKey.
+
+        keys: list of bytes.  Returns (prep_shares [n, (verifier_len+1)*16] u8, status [n] i32)."""
+        n = len(keys)
+        offsets = np.zeros(n + 1, np.uint64)
+        if n:
+            offsets[1:] = np.cumsum([len(r) for r in keys])
+        blob = np.frombuffer(b"".join(keys) + b"\0", dtype=np.uint8)
+        prep = np.zeros((n, 16 * (self.sizes.verifier_len + 1)), np.uint8)
+        status = np.zeros(n, np.int32)
+        vk = np.frombuffer(bytes(verify_key), dtype=np.uint8)
+        self._chk(lib.wh_prio3_prepare_init_batch(self._ctx, vk.ctypes.data, blob.ctypes.data, offsets.ctypes.data, n,
+                                                  prep.ctypes.data, status.ctypes.data), "prepare_init_batch")
+        self.n_last = n
+        return prep, status
+
+    def prepare_finish(self, prep_shares_by_aggregator):
+        """prepare_shares_to_prepare_message + prepare_next for the last prepare_init batch.
+
+        prep_shares_by_aggregator: one [n, (verifier_len+1)*16] array per aggregator, in agg_id order.
+        Returns (prep_msgs [n,16] u8, status [n] i32)."""
+        arrs = [np.ascontiguousarray(a, dtype=np.uint8) for a in prep_shares_by_aggregator]
+        n = self.n_last
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        msgs = np.zeros((n, 16), np.uint8)
+        status = np.zeros(n, np.int32)
+        self._chk(lib.wh_prio3_prepare_finish_batch(self._ctx, ptrs, n, msgs.ctypes.data, status.ctypes.data), "prepare_finish_batch")
+        return msgs, status
 
     def out_shares(self):
         out = np.zeros((self.n_last, 16 * self.sizes.output_len), np.uint8)
