@@ -1,6 +1,7 @@
 // C-ABI layer of libwhisper_gfx950.so (include/whisper_gfx950.h): context, HBM workspace,
 // constant tables and kernel launches.  One context = one GPU = one HIP stream.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -10,11 +11,18 @@
 
 using namespace wh;
 
-namespace wh { void launch_expand(const Prio3Dev &P, const Workspace &W, uint32_t npad, hipStream_t stream); }
+namespace wh {
+void launch_expand(const Prio3Dev &P, const Workspace &W, uint32_t npad, uint32_t sel, hipStream_t stream);
+void launch_meas(const Prio3Dev &P, const Workspace &W, uint32_t mode, uint32_t npad, int32_t *status, hipStream_t stream);
+}
 
 struct wh_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    // side stream for the short kernels that do not depend on the measurement sponges (proof-share
+    // expansion, public-parts hash / RLC / testing id): they slip in beside k_meas
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     wh_prio3_params params{};
     HostSizes z{};
     Prio3Dev P{};
@@ -112,7 +120,7 @@ void aes_tables(const uint8_t key[16], uint8_t out[432]) {
 int32_t alloc_workspace(wh_ctx *c, uint64_t cap) {
     if (cap <= c->cap) return WH_OK;
     Workspace &W = c->W;
-    void *ptrs[] = {W.desc, W.scal, W.weights, W.wlimbs, W.pows, W.rlc, W.hrows, W.hlist, W.llist, W.counters};
+    void *ptrs[] = {W.desc, W.scal, W.weights, W.wlimbs, W.pows, W.rlc, W.hrows, W.hlist, W.llist, W.dirty, W.counters};
     for (void *p : ptrs) if (p) HIPCHK(c, hipFree(p));
     W = Workspace{};
     c->cap = 0;
@@ -129,6 +137,7 @@ int32_t alloc_workspace(wh_ctx *c, uint64_t cap) {
     HIPCHK(c, hipMalloc((void **)&W.hrows, cap * W.hrow_bytes));
     HIPCHK(c, hipMalloc((void **)&W.hlist, cap * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc((void **)&W.llist, cap * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void **)&W.dirty, cap * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc((void **)&W.counters, 64));
     c->cap = cap;
     return WH_OK;
@@ -197,6 +206,9 @@ int32_t wh_ctx_create(int32_t device_id, const wh_prio3_params *params, wh_ctx *
     auto fail = [&](int32_t code) { wh_ctx_destroy(c); return code; };
     if (hipSetDevice(device_id) != hipSuccess) return fail(WH_ERR_HIP);
     if (hipStreamCreate(&c->stream) != hipSuccess) return fail(WH_ERR_HIP);
+    if (hipStreamCreate(&c->stream2) != hipSuccess) return fail(WH_ERR_HIP);
+    if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(WH_ERR_HIP);
+    if (hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) return fail(WH_ERR_HIP);
 
     // constant tables: w^j and s_i = sum_{j=1..calls} w^(ij)
     std::vector<F128> omega(z.m), stab(z.gpoly_len);
@@ -232,12 +244,16 @@ void wh_ctx_destroy(wh_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->stream2) hipStreamSynchronize(c->stream2);
     void *ptrs[] = {c->d_omega, c->d_stab, c->d_aes, c->d_out_shares, c->d_status_own, c->d_keep_eff, c->d_partials,
                     c->d_blob, c->d_offsets, c->d_tags, c->d_ids, c->d_prep, c->W.desc, c->W.scal, c->W.weights, c->W.wlimbs, c->W.pows, c->W.rlc,
-                    c->W.hrows, c->W.hlist, c->W.llist, c->W.counters};
+                    c->W.hrows, c->W.hlist, c->W.llist, c->W.dirty, c->W.counters};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -285,10 +301,28 @@ int32_t wh_prio3_prepare_batch_dev(wh_ctx *c, const uint8_t verify_key[16], cons
         { KTimer t_(c, WH_K_PARSE);
         hipLaunchKernelGGL(k_parse, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, d_blob, d_offsets + base, nb,
                            d_status + base, tags_b, out_b); }
+        // side stream: proof shares, then job B of the hash kernel (both short, independent of k_meas)
+        const bool side = !getenv("WH_NO_SIDE_STREAM");
+        hipStream_t s2 = side ? c->stream2 : c->stream;
+        if (side) {
+            HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        }
+        { KTimer t_(c, WH_K_EXPAND, s2);
+        launch_expand(c->P, c->W, npad, 1, s2); }
+        { KTimer t_(c, WH_K_HASH, s2);
+        hipLaunchKernelGGL(k_hash, dim3(npad / 256), dim3(256), 0, s2, c->P, c->W, npad, 1u, vk0, vk1,
+                           c->d_aes, d_ids + 16 * base, d_status + base); }
+        if (side) HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
+        { KTimer t_(c, WH_K_MEAS);
+        launch_meas(c->P, c->W, 0, npad, d_status + base, c->stream); }     // measurement shares and their sponges
         { KTimer t_(c, WH_K_EXPAND);
-        launch_expand(c->P, c->W, npad, c->stream); }
+        launch_expand(c->P, c->W, npad, 2, c->stream); }                    // (reports with a rejected chunk: none, in practice)
+        { KTimer t_(c, WH_K_MEAS);
+        launch_meas(c->P, c->W, 1, npad, d_status + base, c->stream); }
+        if (side) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         { KTimer t_(c, WH_K_HASH);
-        hipLaunchKernelGGL(k_hash, dim3(2 * npad / 256), dim3(256), 0, c->stream, c->P, c->W, npad, vk0, vk1,
+        hipLaunchKernelGGL(k_hash, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, npad, 0u, vk0, vk1,
                            c->d_aes, d_ids + 16 * base, d_status + base); }
         { KTimer t_(c, WH_K_QUERY);
         hipLaunchKernelGGL(q.fn, dim3(q.polyeval ? (nb + 3) / 4 : nb), dim3(64 * q.waves), q.lds, c->stream, c->P, c->W,
@@ -323,7 +357,7 @@ int32_t wh_prio3_prepare_init_batch_dev(wh_ctx *c, const uint8_t verify_key[16],
     hipLaunchKernelGGL(k_parse_base, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, d_blob, d_offsets, nb, d_status,
                        d_prep, d_out); }
     { KTimer t_(c, WH_K_EXPAND);
-    launch_expand(c->P, c->W, npad, c->stream); }
+    launch_expand(c->P, c->W, npad, 0, c->stream); }
     { KTimer t_(c, WH_K_HASH);
     hipLaunchKernelGGL(k_hash_base, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, vk0, vk1, d_status); }
     { KTimer t_(c, WH_K_QUERY);

@@ -10,13 +10,16 @@ namespace wh {
 // .into_field_vec(n).  Jobs [0, npad) expand the measurement share, jobs [npad, 2 npad) the two
 // proof shares, so a wave never mixes the two shapes.  Every sponge of a lane runs through the
 // same loop body (one copy of the permutation code, small register footprint).
-__global__ void __launch_bounds__(256) k_expand(Prio3Dev P, Workspace W, uint32_t npad) {
+// sel 0: measurement and proof shares of every Helper (draft-07 path); 1: proof shares only (the
+// measurement share comes out of k_meas); 2: measurement shares of the dirty list only.
+__global__ void __launch_bounds__(256) k_expand(Prio3Dev P, Workspace W, uint32_t npad, uint32_t sel) {
     uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t nh = W.counters[0];
     uint32_t which = job >= npad;
     uint32_t slot = which ? job - npad : job;
-    if (slot >= nh) return;
-    const RepDesc d = W.desc[W.hlist[slot]];
+    if (sel == 1 && !which) return;
+    if (sel == 2 && which) return;
+    if (slot >= W.counters[sel == 2 ? 2 : 0]) return;
+    const RepDesc d = W.desc[(sel == 2 ? W.dirty : W.hlist)[slot]];
     // batched report: meas_seed | proof1_seed | jr_blind | proof2_seed; VdafKey: meas_seed | proof_seed | blind
     const uint8_t *seeds = d.seeds;
     Sponge s;
@@ -33,8 +36,8 @@ __global__ void __launch_bounds__(256) k_expand(Prio3Dev P, Workspace W, uint32_
 }
 
 
-void launch_expand(const Prio3Dev &P, const Workspace &W, uint32_t npad, hipStream_t stream) {
-    hipLaunchKernelGGL(k_expand, dim3(2 * npad / 256), dim3(256), 0, stream, P, W, npad);
+void launch_expand(const Prio3Dev &P, const Workspace &W, uint32_t npad, uint32_t sel, hipStream_t stream) {
+    hipLaunchKernelGGL(k_expand, dim3(2 * npad / 256), dim3(256), 0, stream, P, W, npad, sel);
 }
 
 }  // namespace wh

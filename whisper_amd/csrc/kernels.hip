@@ -195,19 +195,21 @@ __device__ __forceinline__ void weights_and_tables(const Prio3Dev &P, const Work
 }
 
 // ---------------------------------------------------------------------------------- hash ----
-// Job A (lanes [0, npad)): six sponges -- own joint-rand part (prio3.rs:2543-2555), joint-rand
+// Job A (lanes [0, npad)): five sponges (the own joint-rand part, prio3.rs:2543-2555, comes from
+//   k_meas) -- joint-rand
 //   seed (derive_joint_rand_seed :482-493 with the own part substituted, :2564-2578), joint
 //   randomness (:2580-2585), own query-rand part (:2610-2642), query-rand seed (:2651-2665, which
 //   reuses DST_JR_SEED), query randomness (:2667-2672) -- then the barycentric weights.
 // Job B (lanes [npad, 2 npad)): hash of the public parts (:2808-2840), RLC coefficients
 //   (:2859-2862), testing id (main.rs:51).
 // All sponges of a lane go through one loop body; a wave-uniform switch picks the inputs.
-__global__ void __launch_bounds__(256) k_hash(Prio3Dev P, Workspace W, uint32_t npad, uint64_t vk0,
+__global__ void __launch_bounds__(256) k_hash(Prio3Dev P, Workspace W, uint32_t npad, uint32_t job_b, uint64_t vk0,
                                               uint64_t vk1, const uint8_t *aes_rk, uint8_t *testing_ids,
                                               int32_t *status) {
     uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t which = job >= npad;
-    uint32_t slot = which ? job - npad : job;
+    // one launch per job: A needs k_meas and the proof shares, B needs nothing but the report
+    uint32_t which = job_b;
+    uint32_t slot = job;
     uint32_t i;
     if (!report_of_slot(W, slot, i) || status[i] != ST_OK) return;
     const RepDesc d = W.desc[i];
@@ -223,16 +225,12 @@ __global__ void __launch_bounds__(256) k_hash(Prio3Dev P, Workspace W, uint32_t 
     F128 sd = f_zero();
     const uint32_t nst = which ? 3 : 6;
 #pragma unroll 1
-    for (uint32_t stg = 0; stg < nst; stg++) {
+    for (uint32_t stg = which ? 0 : 1; stg < nst; stg++) {     // job A's stage 0 (the own joint-rand part) is k_meas
         uint32_t usage = 0, l1 = 0, l2 = 0, l3 = 0, emit_n = 0;
         uint64_t k0 = 0, k1 = 0;
         const uint8_t *p1 = nullptr, *p2 = nullptr, *p3 = nullptr;
         uint8_t *emit_p = nullptr;
         switch (__builtin_amdgcn_readfirstlane(which * 8 + stg)) {
-        case 0:  // own joint-rand part: XOF(blind, 7) . [agg_id] . nonce . enc(meas)
-            usage = DST_JR_PART; k0 = ld64(d.jr_blind); k1 = ld64(d.jr_blind + 8);
-            p1 = d.base + 48; l1 = 1; p2 = nonce; l2 = 16; p3 = d.meas; l3 = 16u * P.input_len;
-            break;
         case 1:  // joint-rand seed over the parts, own part at index role
         case 4: {
             const uint8_t *parts = stg == 1 ? ps_parts : ps2_parts;
@@ -263,10 +261,9 @@ __global__ void __launch_bounds__(256) k_hash(Prio3Dev P, Workspace W, uint32_t 
             xof_emit(s, emit_p, emit_n, P.sampler_bound);
         } else {
             sd = F128{s.st[0], s.st[1]};          // Xof::into_seed
-            if (!which && (stg == 0 || stg == 3)) {
+            if (!which && stg == 3) {
                 // the locally computed part vs the one in the public share (prio3.rs:2790-2805)
-                const uint8_t *theirs = (stg == 0 ? ps_parts : ps2_parts) + 16 * d.role;
-                sc->rand_diff[stg == 3] = !f_eq(sd, ld128(theirs));
+                sc->rand_diff[1] = !f_eq(sd, ld128(ps2_parts + 16 * d.role));
                 st128(own, sd);
             }
         }

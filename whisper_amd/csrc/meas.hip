@@ -1,0 +1,181 @@
+// The measurement-share sponges, in their own translation unit (hipcc 7.2's inliner does not
+// survive all sponge kernels in one).
+//
+// Joint-randomness part of every report (prio3.rs:2543-2555): XOF(blind, 7) . [agg_id] . nonce .
+// enc(meas_share) -> seed, 1561 Keccak-f for the 16384-element share of the bench workload.  For a
+// Helper the share itself is the output of another sponge, XOF(meas_seed, 1) . [agg_id]
+// (prio3.rs:2480-2496), another 1561 Keccak-f.  Both are sequential chains, so their
+// parallelism is the number of reports, and a batch has too few to fill the chip when they run
+// one after the other (k_expand, then the absorb).  Here a Helper gets TWO lanes: the even lane
+// squeezes the share (and stores it for the query kernel), the odd lane absorbs the same words
+// one permutation behind, handed over through DPP; Leader-role reports absorb their share from
+// the report bytes in the same launch.  That is three long lanes per report pair instead of two
+// after one, i.e. ~3 waves per SIMD in one launch.
+//
+// The hand-over assumes that no squeezed 16-byte chunk is rejected by the sampler (probability
+// 2^-59 each): then the absorbed stream is the squeezed stream, 42 bytes (the absorber's prefix)
+// out of phase, and every word index is static.  A pair that sees a rejected chunk puts its report
+// on the dirty list; those reports are redone by the general path (k_expand + mode 1 here).
+#include <hip/hip_runtime.h>
+#include "keccak.hpp"
+#include "prio3_dev.hpp"
+
+namespace wh {
+
+__device__ __forceinline__ uint32_t dpp_prev(uint32_t x) {      // x of lane - 1 (rows of 16 lanes)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+}
+struct W2 { uint32_t lo, hi; };
+__device__ __forceinline__ W2 fetch_prev(uint64_t w) { return W2{dpp_prev((uint32_t)w), dpp_prev((uint32_t)(w >> 32))}; }
+// b ^= ((cur << 16) | (prev >> 48)) & mask: the squeezed stream enters the absorber's block at byte 42 = 5 words + 2 bytes
+__device__ __forceinline__ void xor_shifted(uint64_t &b, const W2 &cur, uint32_t prev_hi, uint32_t m) {
+    const uint32_t vlo = __builtin_amdgcn_alignbit(cur.lo, prev_hi, 16);
+    const uint32_t vhi = __builtin_amdgcn_alignbit(cur.hi, cur.lo, 16);
+    const uint32_t lo = __builtin_amdgcn_bitop3_b32((uint32_t)b, vlo, m, 0x78);           // a ^ (b & c)
+    const uint32_t hi = __builtin_amdgcn_bitop3_b32((uint32_t)(b >> 32), vhi, m, 0x78);
+    b = lo | ((uint64_t)hi << 32);
+}
+
+enum : uint32_t { LANE_FULL = 0, LANE_SQUEEZE = 1, LANE_ABSORB = 2 };
+
+// mode 0: Leader-role reports (whole absorb) and Helper pairs; mode 1: the dirty list (whole absorb from the
+// rows k_expand wrote).
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_meas(Prio3Dev P, Workspace W, uint32_t mode, int32_t *status) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i, kind;
+    if (mode == 1) {
+        if (gid >= W.counters[2]) return;
+        i = W.dirty[gid];
+        kind = LANE_FULL;
+    } else {
+        const uint32_t nl = W.counters[1], nh = W.counters[0], nlpad = (nl + 63) & ~63u;
+        if (gid < nlpad) {
+            if (gid >= nl) return;
+            i = W.llist[gid];
+            kind = LANE_FULL;
+        } else {
+            const uint32_t t = gid - nlpad;
+            if ((t >> 1) >= nh) return;
+            i = W.hlist[t >> 1];
+            kind = (t & 1) ? LANE_ABSORB : LANE_SQUEEZE;
+        }
+    }
+    if (status[i] != ST_OK) return;
+    const RepDesc d = W.desc[i];
+    const uint8_t *agg_id = P.mode ? d.base : d.base + 48;
+    const uint8_t *nonce = P.mode ? d.tail : d.tail + 40 + 32ull * P.verifier_len + 16;
+    const F128 bound = P.sampler_bound;
+
+    Sponge s;
+    const uint8_t *key = kind == LANE_SQUEEZE ? d.seeds : d.jr_blind;
+    s.init_xof(P.alg_id, kind == LANE_SQUEEZE ? DST_MEAS : DST_JR_PART, ld64(key), ld64(key + 8));
+    // the short prefixes never fill a block: [agg_id] for the share stream, [agg_id] . nonce for the part
+    {
+        const uint32_t plen = kind == LANE_SQUEEZE ? 1 : 17;
+        for (uint32_t b = 0; b < plen; b++) {
+            const uint8_t v = b ? nonce[b - 1] : agg_id[0];
+            s.xor_word(s.pos >> 3, (uint64_t)v << (8 * (s.pos & 7)));     // active lanes share pos
+            s.pos++;
+        }
+    }
+    const uint8_t *rest = d.meas;                    // what phase 2 still has to absorb
+    uint32_t rest_len = 16u * P.input_len;
+    uint32_t dirty = 0;
+
+    if (kind != LANE_FULL) {
+        const bool even = kind == LANE_SQUEEZE;
+        const uint32_t m = even ? 0u : ~0u;
+        if (even) s.finalize();                      // first output block
+        uint8_t *out = const_cast<uint8_t *>(d.meas);
+        const uint32_t iters = P.input_len / 21;     // 21 chunks = two rate blocks
+#define WH_PUT(lo_, hi_)                                                                         \
+        do {                                                                                     \
+            const uint64_t l_ = (lo_), h_ = (hi_);                                               \
+            dirty |= even && !(h_ < bound.hi || (h_ == bound.hi && l_ < bound.lo));              \
+            if (even) st128(out, F128{l_, h_});                                                  \
+            out += 16;                                                                           \
+        } while (0)
+#pragma unroll 1
+        for (uint32_t it = 0; it < iters; it++) {
+            W2 t[6];
+            uint32_t prev_hi = 0;
+            // even block e[0..20] is in the squeezer's state: absorber words 5..20 take e[0..15]
+#pragma unroll
+            for (int w = 0; w < 16; w++) {
+                const W2 c = fetch_prev(s.st[w]);
+                xor_shifted(s.st[5 + w], c, prev_hi, m);
+                prev_hi = c.hi;
+            }
+#pragma unroll
+            for (int w = 0; w < 6; w++) t[w] = fetch_prev(s.st[15 + w]);
+#pragma unroll
+            for (int c = 0; c < 10; c++) WH_PUT(s.st[2 * c], s.st[2 * c + 1]);
+            const uint64_t carry = s.st[20];
+            keccak_f1600(s.st);
+            // absorber: words 0..4 of its next block from e[15..20]; then o[0..15] into words 5..20
+#pragma unroll
+            for (int w = 0; w < 5; w++) xor_shifted(s.st[w], t[w + 1], t[w].hi, m);
+            prev_hi = t[5].hi;
+#pragma unroll
+            for (int w = 0; w < 16; w++) {
+                const W2 c = fetch_prev(s.st[w]);
+                xor_shifted(s.st[5 + w], c, prev_hi, m);
+                prev_hi = c.hi;
+            }
+#pragma unroll
+            for (int w = 0; w < 6; w++) t[w] = fetch_prev(s.st[15 + w]);
+            WH_PUT(carry, s.st[0]);
+#pragma unroll
+            for (int c = 0; c < 10; c++) WH_PUT(s.st[2 * c + 1], s.st[2 * c + 2]);
+            keccak_f1600(s.st);
+#pragma unroll
+            for (int w = 0; w < 5; w++) xor_shifted(s.st[w], t[w + 1], t[w].hi, m);
+            xor_shifted(s.st[5], W2{0, 0}, t[5].hi, m);
+        }
+        // the last r < 21 chunks: squeezed word by word, absorbed from memory in phase 2
+        const uint32_t r = P.input_len - 21 * iters;
+        if (even) {
+            uint32_t wpos = 0;
+            for (uint32_t c = 0; c < r; c++) {
+                uint64_t v[2];
+                for (int h = 0; h < 2; h++) {
+                    if (wpos == RATE_WORDS) { keccak_f1600(s.st); wpos = 0; }
+                    v[h] = s.get_word(wpos++);
+                }
+                WH_PUT(v[0], v[1]);
+            }
+        }
+#undef WH_PUT
+        // a rejected chunk anywhere makes the whole hand-over invalid: the absorber reports it
+        dirty = __builtin_amdgcn_update_dpp(0, (int)dirty, 0x111, 0xf, 0xf, false) | dirty;
+        if (even) return;
+        if (dirty) {
+            W.dirty[atomicAdd(&W.counters[2], 1u)] = i;
+            return;
+        }
+        // the squeezer's last stores must be visible to this lane's loads
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+        rest = d.meas + 16ull * 21 * iters;
+        rest_len = 16u * r;
+    }
+    // phase 2: Leader (and mode 1): the whole share; absorber lanes: the tail
+    s.absorb3(rest, rest_len, nullptr, 0, nullptr, 0);
+    s.finalize();
+    const F128 sd = F128{s.st[0], s.st[1]};
+    // the locally computed part vs the one in the public share (prio3.rs:2790-2805); the
+    // descriptor is read again here rather than held in registers across the long loops
+    asm volatile("" ::: "memory");
+    const RepDesc d2 = W.desc[i];
+    RepScal *sc = &W.scal[i];
+    const uint8_t *their_part = (P.mode ? d2.base + 1 : d2.base + 16) + 16 * d2.role;
+    sc->rand_diff[0] = !f_eq(sd, ld128(their_part));
+    sc->own = sd;
+}
+
+void launch_meas(const Prio3Dev &P, const Workspace &W, uint32_t mode, uint32_t npad, int32_t *status, hipStream_t stream) {
+    // mode 0: Leaders (padded to a wavefront) + two lanes per Helper; mode 1: at most npad dirty reports
+    const uint32_t lanes = mode ? npad : 3 * npad + 64;
+    hipLaunchKernelGGL(k_meas, dim3((lanes + 255) / 256), dim3(256), 0, stream, P, W, mode, status);
+}
+
+}  // namespace wh

@@ -83,7 +83,8 @@ struct Workspace {
     uint8_t *hrows;      // [cap][(input_len + 2 proof_len) * 16] expanded Helper shares
     uint32_t *hlist;     // [cap] report index of each Helper slot
     uint32_t *llist;     // [cap] report indices of the Leader-role reports
-    uint32_t *counters;  // [0] = number of Helpers, [1] = number of Leaders (well-formed reports only)
+    uint32_t *dirty;     // [cap] Helper reports whose share stream had a rejected chunk (k_meas), redone the general way
+    uint32_t *counters;  // [0] = number of Helpers, [1] = number of Leaders (well-formed reports only), [2] = dirty
     uint64_t hrow_bytes;
 };
 
