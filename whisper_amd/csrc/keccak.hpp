@@ -230,12 +230,14 @@ struct Sponge {
     // is permuted in exactly one place: steps only XOR and advance `pos`, and a full block
     // (pos == RATE) is permuted at the top of the loop.  Whole rate blocks take the static-index
     // path; the stretch before the first block boundary, seams and tails go word / byte wise.
+    // PREFETCH: loads of the next whole block are issued before the permutation (42 more VGPRs).
+    template <bool PREFETCH = true>
     WH_HD void absorb3(const uint8_t *p, uint32_t len, const uint8_t *p2, uint32_t len2, const uint8_t *p3,
                        uint32_t len3) {
         for (;;) {
             if (pos == SHAKE128_RATE) {
                 // a whole block follows: put its loads in flight under the permutation
-                const bool pre = len >= SHAKE128_RATE;
+                const bool pre = PREFETCH && len >= SHAKE128_RATE;
                 uint64_t w[RATE_WORDS];
                 if (pre) {
 #pragma unroll
