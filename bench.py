@@ -159,8 +159,6 @@ def main():
     # expand and hash have a launch on the side stream whose event time includes waiting for free slots
     dom = max((k for k in kernels if k in per and k not in ("expand",)), key=lambda k: kernels[k]["ms_per_step"])
     launches = kernels[dom]["launches_per_step"]
-    if dom == "meas":
-        launches = 1.0          # the second launch (dirty list) is empty
     avg_ms = kernels[dom]["ms_per_step"] / launches
     bytes_per_launch = per[dom] / launches
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9

@@ -8,7 +8,7 @@ def per_kernel(d):
     acc = defaultdict(list)
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            k = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("wh::", "").split("<")[0]
+            k = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("wh::", "").split("<")[0].strip()
             acc[k].append(float(row["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items() if k.startswith("k_")}
 

@@ -316,10 +316,9 @@ int32_t wh_prio3_prepare_batch_dev(wh_ctx *c, const uint8_t verify_key[16], cons
         if (side) HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
         { KTimer t_(c, WH_K_MEAS);
         launch_meas(c->P, c->W, 0, npad, d_status + base, c->stream); }     // measurement shares and their sponges
-        { KTimer t_(c, WH_K_EXPAND);
-        launch_expand(c->P, c->W, npad, 2, c->stream); }                    // (reports with a rejected chunk: none, in practice)
-        { KTimer t_(c, WH_K_MEAS);
-        launch_meas(c->P, c->W, 1, npad, d_status + base, c->stream); }
+        // reports whose share stream had a rejected chunk (none, in practice): the general path
+        launch_expand(c->P, c->W, npad, 2, c->stream);
+        launch_meas(c->P, c->W, 1, npad, d_status + base, c->stream);
         if (side) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         { KTimer t_(c, WH_K_HASH);
         hipLaunchKernelGGL(k_hash, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, npad, 0u, vk0, vk1,

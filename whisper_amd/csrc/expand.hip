@@ -12,7 +12,7 @@ namespace wh {
 // same loop body (one copy of the permutation code, small register footprint).
 // sel 0: measurement and proof shares of every Helper (draft-07 path); 1: proof shares only (the
 // measurement share comes out of k_meas); 2: measurement shares of the dirty list only.
-__global__ void __launch_bounds__(256) k_expand(Prio3Dev P, Workspace W, uint32_t npad, uint32_t sel) {
+__device__ __forceinline__ void expand_body(const Prio3Dev &P, const Workspace &W, uint32_t npad, uint32_t sel) {
     uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t which = job >= npad;
     uint32_t slot = which ? job - npad : job;
@@ -36,8 +36,12 @@ __global__ void __launch_bounds__(256) k_expand(Prio3Dev P, Workspace W, uint32_
 }
 
 
+__global__ void __launch_bounds__(256) k_expand(Prio3Dev P, Workspace W, uint32_t npad, uint32_t sel) { expand_body(P, W, npad, sel); }
+__global__ void __launch_bounds__(256) k_expand_redo(Prio3Dev P, Workspace W, uint32_t npad) { expand_body(P, W, npad, 2); }
+
 void launch_expand(const Prio3Dev &P, const Workspace &W, uint32_t npad, uint32_t sel, hipStream_t stream) {
-    hipLaunchKernelGGL(k_expand, dim3(2 * npad / 256), dim3(256), 0, stream, P, W, npad, sel);
+    if (sel == 2) hipLaunchKernelGGL(k_expand_redo, dim3(npad / 256), dim3(256), 0, stream, P, W, npad);
+    else hipLaunchKernelGGL(k_expand, dim3(2 * npad / 256), dim3(256), 0, stream, P, W, npad, sel);
 }
 
 }  // namespace wh

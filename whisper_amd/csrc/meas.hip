@@ -40,7 +40,8 @@ enum : uint32_t { LANE_FULL = 0, LANE_SQUEEZE = 1, LANE_ABSORB = 2 };
 
 // mode 0: Leader-role reports (whole absorb) and Helper pairs; mode 1: the dirty list (whole absorb from the
 // rows k_expand wrote).
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_meas(Prio3Dev P, Workspace W, uint32_t mode, int32_t *status) {
+template <uint32_t mode>
+__device__ __forceinline__ void meas_body(const Prio3Dev &P, const Workspace &W, int32_t *status) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t i, kind;
     if (mode == 1) {
@@ -172,10 +173,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     sc->own = sd;
 }
 
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_meas(Prio3Dev P, Workspace W, int32_t *status) {
+    meas_body<0>(P, W, status);
+}
+// the general path for the dirty list (empty unless a share stream had a rejected chunk)
+__global__ void __launch_bounds__(256) k_meas_redo(Prio3Dev P, Workspace W, int32_t *status) { meas_body<1>(P, W, status); }
+
 void launch_meas(const Prio3Dev &P, const Workspace &W, uint32_t mode, uint32_t npad, int32_t *status, hipStream_t stream) {
     // mode 0: Leaders (padded to a wavefront) + two lanes per Helper; mode 1: at most npad dirty reports
-    const uint32_t lanes = mode ? npad : 3 * npad + 64;
-    hipLaunchKernelGGL(k_meas, dim3((lanes + 255) / 256), dim3(256), 0, stream, P, W, mode, status);
+    if (mode) hipLaunchKernelGGL(k_meas_redo, dim3(npad / 256), dim3(256), 0, stream, P, W, status);
+    else hipLaunchKernelGGL(k_meas, dim3((3 * npad + 64 + 255) / 256), dim3(256), 0, stream, P, W, status);
 }
 
 }  // namespace wh
