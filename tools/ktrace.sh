@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/ktrace; rm -rf $out; mkdir -p $out
-( cd $R && timeout -s KILL 240 rocprofv3 --kernel-trace -d $out --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline "$@" > $out/run.log 2>&1 ) || { tail -5 $out/run.log; exit 1; }
+( cd $R && WHISPER_GFX950_LIB=${WHISPER_GFX950_LIB:-} timeout -s KILL 240 rocprofv3 --kernel-trace -d $out --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline "$@" > $out/run.log 2>&1 ) || { tail -5 $out/run.log; exit 1; }
 python3 - $out <<'PY'
 import csv, glob, sys
 rows = []

@@ -301,7 +301,8 @@ int32_t wh_prio3_prepare_batch_dev(wh_ctx *c, const uint8_t verify_key[16], cons
         { KTimer t_(c, WH_K_PARSE);
         hipLaunchKernelGGL(k_parse, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, d_blob, d_offsets + base, nb,
                            d_status + base, tags_b, out_b); }
-        // side stream: proof shares, then job B of the hash kernel (both short, independent of k_meas)
+        // side stream: the Helpers' proof shares (short, independent of k_meas, and harmless beside it:
+        // it runs in the wave slots k_meas leaves; the hash kernel beside k_meas is not)
         const bool side = !getenv("WH_NO_SIDE_STREAM");
         hipStream_t s2 = side ? c->stream2 : c->stream;
         if (side) {
@@ -310,9 +311,6 @@ int32_t wh_prio3_prepare_batch_dev(wh_ctx *c, const uint8_t verify_key[16], cons
         }
         { KTimer t_(c, WH_K_EXPAND, s2);
         launch_expand(c->P, c->W, npad, 1, s2); }
-        { KTimer t_(c, WH_K_HASH, s2);
-        hipLaunchKernelGGL(k_hash, dim3(npad / 256), dim3(256), 0, s2, c->P, c->W, npad, 1u, vk0, vk1,
-                           c->d_aes, d_ids + 16 * base, d_status + base); }
         if (side) HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
         { KTimer t_(c, WH_K_MEAS);
         launch_meas(c->P, c->W, 0, npad, d_status + base, c->stream); }     // measurement shares and their sponges
@@ -321,7 +319,7 @@ int32_t wh_prio3_prepare_batch_dev(wh_ctx *c, const uint8_t verify_key[16], cons
         launch_meas(c->P, c->W, 1, npad, d_status + base, c->stream);
         if (side) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         { KTimer t_(c, WH_K_HASH);
-        hipLaunchKernelGGL(k_hash, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, npad, 0u, vk0, vk1,
+        hipLaunchKernelGGL(k_hash, dim3(2 * npad / 256), dim3(256), 0, c->stream, c->P, c->W, npad, 2u, vk0, vk1,
                            c->d_aes, d_ids + 16 * base, d_status + base); }
         { KTimer t_(c, WH_K_QUERY);
         hipLaunchKernelGGL(q.fn, dim3(q.polyeval ? (nb + 3) / 4 : nb), dim3(64 * q.waves), q.lds, c->stream, c->P, c->W,

@@ -140,7 +140,10 @@ __device__ __forceinline__ uint64_t chi_64(uint64_t a, uint64_t b, uint64_t c) {
 
 WH_HD void keccak_f1600(uint64_t (&a)[25]) {
 #if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll 1
+#ifndef WH_KECCAK_UNROLL
+#define WH_KECCAK_UNROLL 1
+#endif
+#pragma unroll WH_KECCAK_UNROLL
     for (int r = 0; r < 24; r++) WH_KECCAK_ROUND_DEV(a, KECCAK_RC_DEV[r]);
 #else
     for (int r = 0; r < 24; r++) WH_KECCAK_ROUND(a, KECCAK_RC_HOST[r]);

@@ -203,13 +203,13 @@ __device__ __forceinline__ void weights_and_tables(const Prio3Dev &P, const Work
 // Job B (lanes [npad, 2 npad)): hash of the public parts (:2808-2840), RLC coefficients
 //   (:2859-2862), testing id (main.rs:51).
 // All sponges of a lane go through one loop body; a wave-uniform switch picks the inputs.
-__global__ void __launch_bounds__(256) k_hash(Prio3Dev P, Workspace W, uint32_t npad, uint32_t job_b, uint64_t vk0,
+__global__ void __launch_bounds__(256) k_hash(Prio3Dev P, Workspace W, uint32_t npad, uint32_t jobs, uint64_t vk0,
                                               uint64_t vk1, const uint8_t *aes_rk, uint8_t *testing_ids,
                                               int32_t *status) {
     uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
-    // one launch per job: A needs k_meas and the proof shares, B needs nothing but the report
-    uint32_t which = job_b;
-    uint32_t slot = job;
+    // jobs: 0 = A only, 1 = B only, 2 = A in lanes [0, npad) and B in [npad, 2 npad)
+    uint32_t which = jobs == 2 ? job >= npad : jobs;
+    uint32_t slot = (jobs == 2 && which) ? job - npad : job;
     uint32_t i;
     if (!report_of_slot(W, slot, i) || status[i] != ST_OK) return;
     const RepDesc d = W.desc[i];
