@@ -285,6 +285,22 @@ def test_device_pointer_path_and_large_batch_properties():
         assert not d_agg.cpu().numpy().any()
     finally:
         vdaf.close()
+    # the same batch in four sub-batches (workspace reused, side stream forked and joined per sub-batch)
+    import os
+    os.environ["WH_MAX_SUBBATCH"] = "700"
+    vdaf = W.Prio3(p)
+    try:
+        d_tags2 = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+        d_status.fill_(-99)
+        vdaf.prepare_batch_dev(VK, d_blob.data_ptr(), d_off.data_ptr(), n, d_tags2.data_ptr(), d_ids.data_ptr(), d_status.data_ptr())
+        vdaf.aggregate_dev(None, d_agg.data_ptr())
+        vdaf.synchronize()
+        assert not d_status.cpu().numpy().any()
+        assert np.array_equal(d_tags2.cpu().numpy().reshape(n, 16), tags)
+        assert d_agg.cpu().numpy().tobytes() == want
+    finally:
+        del os.environ["WH_MAX_SUBBATCH"]
+        vdaf.close()
 
 
 def test_sum_rows_and_hh_bucket_sum():

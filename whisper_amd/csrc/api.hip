@@ -149,6 +149,10 @@ uint64_t pick_cap(const wh_ctx *c, uint64_t n) {
     uint64_t by_mem = (64ull << 30) / (hrow + 4096);   // <= 64 GiB of expansion rows (288 GB HBM)
     uint64_t cap = 1ull << 19;
     if (cap > by_mem) cap = by_mem;
+    if (const char *e = getenv("WH_MAX_SUBBATCH")) {      // tuning / test knob: reports per sub-batch
+        const uint64_t v = strtoull(e, nullptr, 10);
+        if (v >= 64 && v < cap) cap = v;
+    }
     if (cap < 64) cap = 64;
     if (n <= cap) return n < 64 ? 64 : n;
     // equal-sized sub-batches, so that the last one does not leave the chip half empty
