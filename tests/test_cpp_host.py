@@ -1,0 +1,30 @@
+"""The C++ host mirror (whisper_amd/host/whisper_host.hpp: ClientProofTag, general_binary_split_test,
+run_vdaf_prepare with the reference's names) through its own C++ test programs."""
+import os
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CPP = os.path.join(HERE, "cpp")
+
+
+def _binary(name):
+    path = os.path.join(CPP, "bin", name)
+    if not os.path.exists(path):
+        subprocess.run(["make", "-C", CPP, os.path.join("bin", name)], check=True, capture_output=True)
+    return path
+
+
+def test_group_testing_cpp_reference_scenario():
+    """common/src/grouptest.rs:373-447 (300 tags, 3 corrupted, 2 deleted), both parties as threads."""
+    r = subprocess.run([_binary("test_grouptest")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_run_vdaf_prepare_cpp_two_servers():
+    """server-batch-prio3/src/main.rs:65-125 on two GPU contexts: tampered clients rejected by both
+    servers, aggregate shares unshard to the honest sum."""
+    r = subprocess.run([_binary("test_run_vdaf_prepare")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
