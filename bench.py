@@ -74,11 +74,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the measured path)")
+    # WH_BENCH_BACKEND=gloo rehearses the N > 1 path with several ranks on one GPU (RCCL wants one GPU per rank)
+    backend = os.environ.get("WH_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     wl = WORKLOADS[args.workload]
     n = args.reports_per_gpu or wl["reports_per_gpu"]
@@ -142,7 +149,7 @@ def main():
     ktimes = vdaf.kernel_times(reset=True)
     vdaf.set_profiling(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     n_bad_status = int((d_status != 0).sum().item())

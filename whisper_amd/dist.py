@@ -23,6 +23,11 @@ def all_gather_partials(partial, group=None):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return partial.reshape(1, -1).clone()
+    if partial.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal backend (CPU tests, several ranks on one GPU): gloo gathers host tensors only
+        host = torch.empty(world * partial.numel(), dtype=torch.uint8)
+        dist.all_gather_into_tensor(host, partial.contiguous().cpu(), group=group)
+        return host.to(partial.device).reshape(world, -1)
     out = torch.empty(world * partial.numel(), dtype=torch.uint8, device=partial.device)
     dist.all_gather_into_tensor(out, partial.contiguous(), group=group)
     return out.reshape(world, -1)
