@@ -141,6 +141,11 @@ int32_t wh_f128_sum_rows_dev(wh_ctx *ctx, const uint8_t *d_rows, uint64_t n_rows
  * buckets[n][words] with words = num_buckets * 258 (256 data + sign + ctr); acc[words]. */
 int32_t wh_hh_bucket_sum_u32_dev(wh_ctx *ctx, const uint32_t *d_buckets, const uint8_t *d_keep, uint64_t n,
                                  uint64_t words, uint32_t *d_acc);
+/* replaces: the `streaming` loop of server-hh (server-hh/src/main.rs:113-216), which feeds `batch_size` clients at a
+ * time and adds each slice's bucket vector into the running sketch (CountSketch::insert, countsketch.rs:22-28):
+ * same sum, but d_acc is added to instead of being overwritten. */
+int32_t wh_hh_bucket_accumulate_u32_dev(wh_ctx *ctx, const uint32_t *d_buckets, const uint8_t *d_keep, uint64_t n,
+                                        uint64_t words, uint32_t *d_acc);
 
 int32_t wh_ctx_synchronize(wh_ctx *ctx);
 

@@ -243,6 +243,40 @@ def test_end_to_end_group_test_identifies_bad_clients():
         vdaf.close()
 
 
+def test_config_c1_thousand_clients_hundred_bad():
+    """BASELINE configs[0] / SURVEY C1 at full size: SumVec bits 16, vec_size 128, chunk_size 64 (the reference's
+    configs/prio3-server-{alice,bob}.json), 1000 clients of which 100 are tampered on Bob's copy; both servers'
+    tags against the oracle, host group test, aggregate of the 900 honest clients."""
+    p = W.Prio3Params(W.SUMVEC, 16, 128, 64)
+    op = O.params(W.SUMVEC, 16, 128, 64)
+    n = 1000
+    rnd = np.random.default_rng(1)
+    bad = set(int(x) for x in rnd.choice(n, 100, replace=False))
+    lr, hr, meas = make_reports(p, n, seed=1234, nthreads=8)
+    alice, bob = server_views(lr, hr, bad)
+    vdaf = W.Prio3(p)
+    try:
+        views = []
+        for reports in (alice, bob):
+            tags, ids, status = vdaf.prepare_encoded_keys(VK, reports)
+            o_tags, o_ids, o_status, _ = oracle_batch(op, reports)
+            assert not status.any() and np.array_equal(tags, o_tags) and np.array_equal(ids, o_ids)
+            tid = [int.from_bytes(ids[i].tobytes(), "little") for i in range(n)]
+            order = sorted(range(n), key=lambda i: tid[i])
+            views.append((tid, [W.ClientProofTag(tid[i], tags[i].tobytes()) for i in order]))
+        bad_a, bad_b, _ = W.general_binary_split_test(views[0][1], views[1][1], VK, len(bad), 16)
+        want_ids = {views[0][0][i] for i in bad}
+        assert bad_a == want_ids and bad_b == want_ids
+        aggs = []
+        for reports, (tid, _) in zip((alice, bob), views):
+            vdaf.prepare_encoded_keys(VK, reports)
+            aggs.append(vdaf.aggregate(np.array([tid[i] not in bad_a for i in range(n)], np.uint8)))
+        good = [i for i in range(n) if i not in bad]
+        assert W.Prio3.unshard(aggs) == [int(sum(int(meas[i][e]) for i in good)) for e in range(128)]
+    finally:
+        vdaf.close()
+
+
 def test_device_pointer_path_and_large_batch_properties():
     """Inputs resident in HBM (torch tensors own the memory), sub-batching, and size-independent
     properties at a size the oracle is only sampled on: duplicated reports give identical tags,
@@ -328,5 +362,13 @@ def test_sum_rows_and_hh_bucket_sum():
                 vdaf.hh_bucket_sum_u32_dev(d_b.data_ptr(), dk, n, words, d_acc.data_ptr())
                 vdaf.synchronize()
                 assert np.array_equal(d_acc.cpu().numpy().view(np.uint32), O.hh_bucket_sum_u32(buckets, kp))
+            # streaming (server-hh/src/main.rs:113-216, `batch_size` slices): the accumulator carries over
+            step = max(1, n // 3)
+            for lo in range(0, n, step):
+                m = min(step, n - lo)
+                vdaf.hh_bucket_sum_u32_dev(d_b[lo:lo + m].data_ptr(), d_k[lo:lo + m].data_ptr(), m, words, d_acc.data_ptr(),
+                                           accumulate=lo > 0)
+            vdaf.synchronize()
+            assert np.array_equal(d_acc.cpu().numpy().view(np.uint32), O.hh_bucket_sum_u32(buckets, keep))
     finally:
         vdaf.close()

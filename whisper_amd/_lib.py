@@ -40,7 +40,7 @@ EXPORTS = [
     "wh_ctx_synchronize", "wh_client_shard_batched", "wh_client_shard_many", "wh_test_f128_op",
     "wh_test_xof_expand", "wh_ctx_set_profiling", "wh_ctx_kernel_times",
     "wh_ctx_set_test_sampler_bound", "wh_client_set_test_sampler_bound",
-    "wh_prio3_prepare_init_batch_dev", "wh_prio3_prepare_init_batch", "wh_prio3_prepare_finish_batch",
+    "wh_hh_bucket_accumulate_u32_dev", "wh_prio3_prepare_init_batch_dev", "wh_prio3_prepare_init_batch", "wh_prio3_prepare_finish_batch",
 ]
 
 vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32
@@ -59,6 +59,7 @@ lib.wh_prio3_aggregate_dev.argtypes = [vp, vp, vp]
 lib.wh_prio3_aggregate.argtypes = [vp, vp, vp]
 lib.wh_f128_sum_rows_dev.argtypes = [vp, vp, u64, u32, vp, vp]
 lib.wh_hh_bucket_sum_u32_dev.argtypes = [vp, vp, vp, u64, u64, vp]
+lib.wh_hh_bucket_accumulate_u32_dev.argtypes = [vp, vp, vp, u64, u64, vp]
 lib.wh_ctx_synchronize.argtypes = [vp]
 lib.wh_client_shard_batched.argtypes = [C.POINTER(Params), vp, vp, vp, vp, vp, vp]
 lib.wh_client_shard_many.argtypes = [C.POINTER(Params), vp, u32, vp, vp, u64, u64, u32, vp, vp]

@@ -530,11 +530,11 @@ int32_t wh_f128_sum_rows_dev(wh_ctx *c, const uint8_t *d_rows, uint64_t n_rows, 
     return sum_rows(c, reinterpret_cast<const F128 *>(d_rows), d_keep, n_rows, len, reinterpret_cast<F128 *>(d_out));
 }
 
-int32_t wh_hh_bucket_sum_u32_dev(wh_ctx *c, const uint32_t *d_buckets, const uint8_t *d_keep, uint64_t n, uint64_t words,
-                                 uint32_t *d_acc) {
+static int32_t hh_sum(wh_ctx *c, const uint32_t *d_buckets, const uint8_t *d_keep, uint64_t n, uint64_t words,
+                      uint32_t *d_acc, bool zero_first) {
     if (!c || !d_acc || !words || (n && !d_buckets)) return WH_ERR_PARAM;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemsetAsync(d_acc, 0, words * 4, c->stream));
+    if (zero_first) HIPCHK(c, hipMemsetAsync(d_acc, 0, words * 4, c->stream));
     if (!n) return WH_OK;
     const uint32_t gx = (uint32_t)((words + 4 * 256 - 1) / (4 * 256));
     // enough (x, y) blocks to fill the chip: target ~4096 blocks
@@ -545,6 +545,14 @@ int32_t wh_hh_bucket_sum_u32_dev(wh_ctx *c, const uint32_t *d_buckets, const uin
     hipLaunchKernelGGL(k_hh_sum_u32, dim3(gx, gy), dim3(256), 0, c->stream, d_buckets, d_keep, n, words, cpb, d_acc); }
     HIPCHK(c, hipGetLastError());
     return WH_OK;
+}
+int32_t wh_hh_bucket_sum_u32_dev(wh_ctx *c, const uint32_t *d_buckets, const uint8_t *d_keep, uint64_t n, uint64_t words,
+                                 uint32_t *d_acc) {
+    return hh_sum(c, d_buckets, d_keep, n, words, d_acc, true);
+}
+int32_t wh_hh_bucket_accumulate_u32_dev(wh_ctx *c, const uint32_t *d_buckets, const uint8_t *d_keep, uint64_t n, uint64_t words,
+                                        uint32_t *d_acc) {
+    return hh_sum(c, d_buckets, d_keep, n, words, d_acc, false);
 }
 
 int32_t wh_ctx_set_profiling(wh_ctx *c, int32_t on) {

@@ -189,8 +189,9 @@ class Prio3:
     def sum_rows_dev(self, d_rows, n_rows, length, d_keep, d_out):
         self._chk(lib.wh_f128_sum_rows_dev(self._ctx, d_rows, n_rows, length, d_keep, d_out), "sum_rows_dev")
 
-    def hh_bucket_sum_u32_dev(self, d_buckets, d_keep, n, words, d_acc):
-        self._chk(lib.wh_hh_bucket_sum_u32_dev(self._ctx, d_buckets, d_keep, n, words, d_acc), "hh_bucket_sum")
+    def hh_bucket_sum_u32_dev(self, d_buckets, d_keep, n, words, d_acc, accumulate=False):
+        fn = lib.wh_hh_bucket_accumulate_u32_dev if accumulate else lib.wh_hh_bucket_sum_u32_dev
+        self._chk(fn(self._ctx, d_buckets, d_keep, n, words, d_acc), "hh_bucket_sum")
 
     # ---- measurement ----
     KERNELS = ("parse", "expand", "hash", "query", "aggregate", "hh_sum", "meas")
