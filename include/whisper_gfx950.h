@@ -123,6 +123,22 @@ int32_t wh_prio3_prepare_init_batch(wh_ctx *ctx, const uint8_t verify_key[16], c
 int32_t wh_prio3_prepare_finish_batch(wh_ctx *ctx, const uint8_t *const *prep_shares, uint64_t n, uint8_t *prep_msgs,
                                       int32_t *status);
 
+/* ---- the flp::Type surface (batched-flpcp-rs/src/flp.rs:186-196) ---- */
+/* replaces: Type::query (flp.rs:359-479) for n independent (input, proof, query_rand, joint_rand) tuples, all of this
+ * context's circuit; HOST buffers of n rows each: input[input_len], proof[proof_len], query_rand[1],
+ * joint_rand[joint_rand_len] elements.  verifier: n * verifier_len elements.  status per tuple: WH_ERR_QUERY_RAND
+ * when query_rand is an m-th root of unity (FlpError::Query), WH_ERR_MODULUS for non-canonical elements.
+ * Type::truncate (types.rs:641-648, 439-442, 280-284) of every input is left in the context: wh_prio3_out_shares. */
+int32_t wh_flp_query_batch(wh_ctx *ctx, const uint8_t *input, const uint8_t *proof, const uint8_t *query_rand,
+                           const uint8_t *joint_rand, uint32_t num_shares, uint64_t n, uint8_t *verifier, int32_t *status);
+/* replaces: Type::decide (flp.rs:483-512) for n verifiers: decision[i] = 1 accept, 0 reject, WH_ERR_MODULUS. */
+int32_t wh_flp_decide_batch(wh_ctx *ctx, const uint8_t *verifier, uint64_t n, int32_t *decision);
+/* replaces (CPU, client side): Type::encode_measurement (types.rs:582-606, 388-399, 246-253) and Type::prove
+ * (flp.rs:231-347) with num_shares = 1; prove_rand: arity elements, joint_rand: joint_rand_len elements. */
+int32_t wh_flp_encode(const wh_prio3_params *params, const uint64_t *measurement, uint8_t *input);
+int32_t wh_flp_prove(const wh_prio3_params *params, const uint8_t *input, const uint8_t *prove_rand,
+                     const uint8_t *joint_rand, uint8_t *proof);
+
 /* ---- aggregation ---- */
 /* replaces: the merge loop over reports whose testing id is not in the bad set
  * (server-batch-prio3/src/main.rs:108-118, 173-183; Aggregatable::merge vdaf.rs:658-676;

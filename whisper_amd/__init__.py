@@ -8,6 +8,6 @@ call fails if no GPU is present.
 from ._lib import lib, LIB_PATH, WhError  # noqa: F401
 from .prio3 import (  # noqa: F401
     Prio3, Prio3Params, new_sum_vec_256, new_histogram_256, new_average_256, shard_batched_many,
-    client_set_test_sampler_bound, SUMVEC, HISTOGRAM, AVERAGE,
+    client_set_test_sampler_bound, flp_encode, flp_prove, SUMVEC, HISTOGRAM, AVERAGE,
 )
 from .grouptest import general_binary_split_test, ClientProofTag  # noqa: F401

@@ -278,7 +278,8 @@ int32_t wh_prio3_prepare_batch_dev(wh_ctx *c, const uint8_t verify_key[16], cons
     HIPCHK(c, hipSetDevice(c->device));
     const HostSizes &z = c->z;
     int32_t rc;
-    c->P.mode = 0;
+    c->P.mode = 0; c->P.ver_stride = 0;
+    c->P.half = f_inv(f_small(2));
     // allocations first (none inside the launch sequence once the context is warm)
     if ((rc = alloc_workspace(c, pick_cap(c, n)))) return rc;
     if ((rc = ensure(c, c->d_out_shares, c->out_cap, (n ? n : 1) * (uint64_t)z.output_len))) return rc;
@@ -340,7 +341,8 @@ int32_t wh_prio3_prepare_init_batch_dev(wh_ctx *c, const uint8_t verify_key[16],
     HIPCHK(c, hipSetDevice(c->device));
     const HostSizes &z = c->z;
     int32_t rc;
-    c->P.mode = 1;
+    c->P.mode = 1; c->P.ver_stride = z.verifier_len + 1;
+    c->P.half = f_inv(f_small(c->params.num_aggregators));
     if ((rc = alloc_workspace(c, pick_cap(c, n)))) return rc;
     if ((rc = ensure(c, c->d_out_shares, c->out_cap, (n ? n : 1) * (uint64_t)z.output_len))) return rc;
     if (n > c->cap) { c->err = "prepare_init keeps its state in the workspace: one sub-batch only"; return WH_ERR_UNSUPPORTED; }
@@ -428,6 +430,66 @@ int32_t wh_prio3_prepare_finish_batch(wh_ctx *c, const uint8_t *const *prep_shar
     hipFree(d_all); hipFree(d_msgs); hipFree(d_ptrs);
     if (!rc && e != hipSuccess) { c->err = hipGetErrorString(e); rc = WH_ERR_HIP; }
     return rc;
+}
+
+int32_t wh_flp_query_batch(wh_ctx *c, const uint8_t *input, const uint8_t *proof, const uint8_t *query_rand,
+                           const uint8_t *joint_rand, uint32_t num_shares, uint64_t n, uint8_t *verifier, int32_t *status) {
+    if (!c || !num_shares || (n && (!input || !proof || !query_rand || !joint_rand || !verifier || !status))) return WH_ERR_PARAM;
+    if (n > 0xfffffff0ull) return WH_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    const HostSizes &z = c->z;
+    int32_t rc;
+    c->P.mode = 2; c->P.ver_stride = z.verifier_len;
+    c->P.half = f_inv(f_small(num_shares));
+    if ((rc = alloc_workspace(c, pick_cap(c, n)))) return rc;
+    if (n > c->cap) { c->err = "flp query: one sub-batch only"; return WH_ERR_UNSUPPORTED; }
+    if ((rc = ensure(c, c->d_out_shares, c->out_cap, (n ? n : 1) * (uint64_t)z.output_len))) return rc;
+    c->n_last = n;
+    if (!n) return WH_OK;
+    const QueryLaunch q = query_launch(c, true);
+    if (!q.fn) { c->err = "circuit has too many gadget calls for the query kernel's LDS rows"; return WH_ERR_UNSUPPORTED; }
+    const uint64_t in_b = 16ull * z.input_len * n, pf_b = 16ull * z.proof_len * n, jr_b = 16ull * z.jr_len * n, ver_b = 16ull * z.verifier_len * n;
+    if ((rc = ensure(c, c->d_blob, c->blob_cap, in_b + pf_b + 16 * n + jr_b + 64))) return rc;
+    if ((rc = ensure(c, c->d_prep, c->prep_cap, ver_b))) return rc;
+    if ((rc = ensure(c, c->d_status_own, c->status_cap, n))) return rc;
+    uint8_t *d_in = c->d_blob, *d_pf = d_in + in_b, *d_qr = d_pf + pf_b, *d_jr = d_qr + 16 * n;
+    HIPCHK(c, hipMemcpyAsync(d_in, input, in_b, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_pf, proof, pf_b, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_qr, query_rand, 16 * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_jr, joint_rand, jr_b, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->W.counters, 0, 64, c->stream));
+    c->d_status_last = c->d_status_own;
+    const uint32_t nb = (uint32_t)n, npad = (nb + 255) / 256 * 256;
+    hipLaunchKernelGGL(k_flp_setup, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, d_in, d_pf, d_qr, d_jr, nb, c->d_status_own);
+    hipLaunchKernelGGL(q.fn, dim3(q.polyeval ? (nb + 3) / 4 : nb), dim3(64 * q.waves), q.lds, c->stream, c->P, c->W, c->d_prep,
+                       reinterpret_cast<uint8_t *>(c->d_out_shares), c->d_status_own);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(verifier, c->d_prep, ver_b, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(status, c->d_status_own, 4 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return WH_OK;
+}
+
+int32_t wh_flp_decide_batch(wh_ctx *c, const uint8_t *verifier, uint64_t n, int32_t *decision) {
+    if (!c || (n && (!verifier || !decision))) return WH_ERR_PARAM;
+    if (n > 0xfffffff0ull) return WH_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!n) return WH_OK;
+    const uint64_t ver_b = 16ull * c->z.verifier_len * n;
+    uint8_t *d_v = nullptr; int32_t *d_ok = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_v, ver_b));
+    HIPCHK(c, hipMalloc((void **)&d_ok, 4 * n));
+    hipError_t e = hipMemcpyAsync(d_v, verifier, ver_b, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_flp_decide, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, c->stream, c->P, d_v, (uint32_t)n, d_ok);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(decision, d_ok, 4 * n, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e2 = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = e2;
+    hipFree(d_v); hipFree(d_ok);
+    if (e != hipSuccess) { c->err = hipGetErrorString(e); return WH_ERR_HIP; }
+    return WH_OK;
 }
 
 int32_t wh_prio3_prepare_batch(wh_ctx *c, const uint8_t verify_key[16], const uint8_t *blob, const uint64_t *offsets,

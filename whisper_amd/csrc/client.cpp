@@ -260,3 +260,33 @@ extern "C" void wh_client_set_test_sampler_bound(const uint8_t bound[16]) {
     }
     g_sampler_bound = b;
 }
+
+// ---- flp::Type surface on the CPU (the prover is client-side work) ----
+extern "C" int32_t wh_flp_encode(const wh_prio3_params *params, const uint64_t *measurement, uint8_t *input) {
+    HostSizes z;
+    if (!params || !measurement || !input) return WH_ERR_PARAM;
+    int32_t rc = host_sizes(*params, z);
+    if (rc) return rc;
+    Vec x;
+    if ((rc = encode_measurement(*params, z, measurement, x))) return rc;
+    memcpy(input, x.data(), 16 * x.size());
+    return WH_OK;
+}
+extern "C" int32_t wh_flp_prove(const wh_prio3_params *params, const uint8_t *input, const uint8_t *prove_rand,
+                                const uint8_t *joint_rand, uint8_t *proof) {
+    Flp flp;
+    if (!params || !input || !prove_rand || !joint_rand || !proof) return WH_ERR_PARAM;
+    flp.p = *params;
+    int32_t rc = host_sizes(flp.p, flp.z);
+    if (rc) return rc;
+    const HostSizes &z = flp.z;
+    Vec x(z.input_len), pr(z.arity), jr(z.jr_len), out, fcoef, fv;
+    memcpy(x.data(), input, 16 * x.size());
+    memcpy(pr.data(), prove_rand, 16 * pr.size());
+    memcpy(jr.data(), joint_rand, 16 * jr.size());
+    for (const Vec *v : {&x, &pr, &jr})
+        for (const F128 &e : *v) if (!f_in_range(e.lo, e.hi)) return WH_ERR_MODULUS;
+    flp.prove(x, pr, jr.data(), out, fcoef, fv);
+    memcpy(proof, out.data(), 16 * out.size());
+    return WH_OK;
+}

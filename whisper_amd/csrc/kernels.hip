@@ -350,8 +350,8 @@ __global__ void k_parse_base(Prio3Dev P, Workspace W, const uint8_t *blob, const
     if (st) {
         F128 *out_row = reinterpret_cast<F128 *>(out_shares) + (uint64_t)i * P.output_len;
         for (uint32_t e = 0; e < P.output_len; e++) out_row[e] = f_zero();
-        F128 *prep = reinterpret_cast<F128 *>(prep_shares) + (uint64_t)i * (P.verifier_len + 1);
-        for (uint32_t e = 0; e <= P.verifier_len; e++) prep[e] = f_zero();
+        F128 *prep = reinterpret_cast<F128 *>(prep_shares) + (uint64_t)i * P.ver_stride;
+        for (uint32_t e = 0; e < P.ver_stride; e++) prep[e] = f_zero();
     }
     W.desc[i] = d;
     status[i] = st;
@@ -463,6 +463,64 @@ __global__ void __launch_bounds__(256) k_finish_base(Prio3Dev P, Workspace W, co
     }
 }
 
+// ------------------------------------------------------ flp::Type::query / decide, bare ----
+// Type::query (flp.rs:359-479) on caller-supplied inputs: input[n][input_len], proof[n][proof_len],
+// query_rand[n][1], joint_rand[n][jr_len].  This kernel stands in for parse + hash: descriptors that
+// point at the rows, the randomness where the query kernels read it, and the per-report tables.
+__global__ void __launch_bounds__(256) k_flp_setup(Prio3Dev P, Workspace W, const uint8_t *input, const uint8_t *proof,
+                                                   const uint8_t *query_rand, const uint8_t *joint_rand, uint32_t n,
+                                                   int32_t *status) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { W.counters[1] = n; W.counters[0] = 0; }
+    if (i >= n) return;
+    W.llist[i] = i;
+    RepDesc d;
+    d.base = d.tail = d.jr_blind = d.seeds = d.proof1 = nullptr; d.role = 0; d.hslot = 0;
+    d.meas = input + 16ull * P.input_len * i;
+    d.proof2 = proof + 16ull * P.proof_len * i;
+    W.desc[i] = d;
+    RepScal *sc = &W.scal[i];
+    int32_t st = ST_OK;
+    const F128 r = ld128(query_rand + 16ull * i);
+    if (!f_in_range(r.lo, r.hi)) st = ST_ERR_MODULUS;
+    for (uint32_t q = 0; q < P.jr_len; q++) {
+        const F128 v = ld128(joint_rand + 16ull * (P.jr_len * (uint64_t)i + q));
+        if (!f_in_range(v.lo, v.hi)) st = ST_ERR_MODULUS;
+        sc->jr[P.jr_len + q] = v;
+    }
+    sc->qr[0] = sc->qr[1] = r;
+    sc->own = f_zero();
+    if (!st) {
+        const F128 rm = f_sqr_n(r, P.log2m);
+        if (f_eq(rm, f_one())) st = ST_ERR_QUERY_RAND;                       // flp.rs:413-419
+        else weights_and_tables(P, W, i, r, rm, sc->jr[P.jr_len]);
+    }
+    status[i] = st;
+}
+
+// Type::decide (flp.rs:483-512) on n verifiers of verifier_len elements: one wavefront each.
+__global__ void __launch_bounds__(256) k_flp_decide(Prio3Dev P, const uint8_t *verifiers, uint32_t n, int32_t *ok_out) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t i = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (i >= n) return;
+    const uint8_t *v = verifiers + 16ull * P.verifier_len * i;
+    uint32_t bad = 0;
+    bool ok;
+    auto el = [&](uint32_t e) { F128 x = ld128(v + 16ull * e); bad |= !f_in_range(x.lo, x.hi); return x; };
+    if (P.circuit == CIRCUIT_AVERAGE) {
+        F128 a = el(0), b = el(1), c = el(2);
+        ok = f_is_zero(a) && f_eq(f_sub(f_sqr(b), b), c);
+    } else {
+        F128 acc = f_zero();
+        for (uint32_t k = lane; k < P.chunk; k += 64) acc = f_add(acc, f_mul(el(1 + 2 * k), el(2 + 2 * k)));
+        acc = wave_sum(acc);
+        F128 first = el(0), last = el(1 + P.arity);
+        ok = f_is_zero(first) && f_eq(acc, last);
+    }
+    bad = wave_or(bad);
+    if (lane == 0) ok_out[i] = bad ? ST_ERR_MODULUS : (ok ? 1 : 0);
+}
+
 // --------------------------------------------------------------------------------- query ----
 // One workgroup of S = blockDim.x / 64 wavefronts per report.  Type::query for the
 // ParallelSum<Mul> circuits (flp.rs:359-479, types.rs:623-639, 410-437, 742-777) in barycentric
@@ -525,11 +583,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     uint32_t i;
     if (!report_of_slot(W, blockIdx.x, i)) return;
     uint8_t *tag_out = tags + 16ull * i;
-    F128 *ver_row = reinterpret_cast<F128 *>(tags) + (uint64_t)i * (P.verifier_len + 1);    // BASE
+    F128 *ver_row = reinterpret_cast<F128 *>(tags) + (uint64_t)i * P.ver_stride;            // BASE
     F128 *out_row = reinterpret_cast<F128 *>(out_shares) + (uint64_t)i * P.output_len;
     if (status[i] != ST_OK) {               // uniform over the workgroup
         for (uint32_t e = threadIdx.x; e < P.output_len; e += blockDim.x) out_row[e] = f_zero();
-        if (BASE) for (uint32_t e = threadIdx.x; e <= P.verifier_len; e += blockDim.x) ver_row[e] = f_zero();
+        if (BASE) for (uint32_t e = threadIdx.x; e < P.ver_stride; e += blockDim.x) ver_row[e] = f_zero();
         else if (threadIdx.x == 0) st128(tag_out, f_zero());
         return;
     }
@@ -745,7 +803,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     for (uint32_t w = 0; w < S; w++) bad |= sh->bad[w];
     if (bad) {
         for (uint32_t e = threadIdx.x; e < P.output_len; e += blockDim.x) out_row[e] = f_zero();
-        if (BASE) for (uint32_t e = threadIdx.x; e <= P.verifier_len; e += blockDim.x) ver_row[e] = f_zero();
+        if (BASE) for (uint32_t e = threadIdx.x; e < P.ver_stride; e += blockDim.x) ver_row[e] = f_zero();
     }
     if (threadIdx.x == 0) {
         const uint32_t vl = P.verifier_len;
@@ -760,7 +818,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         if (BASE) {
             // Prio3PrepareShare (prio3.rs:1953-1970): verifier share | joint-rand part
             if (bad) status[i] = ST_ERR_MODULUS;
-            else { ver_row[0] = v0; ver_row[1 + P.arity] = g_at_r; ver_row[vl] = sc->own; }
+            else { ver_row[0] = v0; ver_row[1 + P.arity] = g_at_r; if (P.ver_stride > vl) ver_row[vl] = sc->own; }
             return;
         }
         F128 q0 = ld128g(pp1), qg = ld128g(pp1 + 16ull * (1 + P.arity));
@@ -797,12 +855,12 @@ __global__ void __launch_bounds__(256) k_query_polyeval(Prio3Dev P, Workspace W,
     uint32_t i;
     if (!report_of_slot(W, slot, i)) return;
     uint8_t *tag_out = tags + 16ull * i;
-    F128 *ver_row = reinterpret_cast<F128 *>(tags) + (uint64_t)i * 4;     // BASE: verifier[3] | joint-rand part
+    F128 *ver_row = reinterpret_cast<F128 *>(tags) + (uint64_t)i * P.ver_stride;   // BASE: verifier[3] (| joint-rand part)
     F128 *out_row = reinterpret_cast<F128 *>(out_shares) + (uint64_t)i;   // output_len == 1
     if (status[i] != ST_OK) {
         if (lane == 0) {
             out_row[0] = f_zero();
-            if (BASE) { for (int e = 0; e < 4; e++) ver_row[e] = f_zero(); }
+            if (BASE) { for (uint32_t e = 0; e < P.ver_stride; e++) ver_row[e] = f_zero(); }
             else st128(tag_out, f_zero());
         }
         return;
@@ -882,7 +940,7 @@ __global__ void __launch_bounds__(256) k_query_polyeval(Prio3Dev P, Workspace W,
             if (bad) { status[i] = ST_ERR_MODULUS; out = f_zero(); v0 = v1 = g_at_r = f_zero(); }
             out_row[0] = out;
             ver_row[0] = v0; ver_row[1] = v1; ver_row[2] = g_at_r;
-            ver_row[3] = bad ? f_zero() : sc->own;
+            if (P.ver_stride > 3) ver_row[3] = bad ? f_zero() : sc->own;
         }
         return;
     }

@@ -29,7 +29,8 @@ struct Prio3Dev {
     uint32_t leader_len, helper_len;  // encoded report sizes
     uint32_t n_weights;               // calls + 1
     uint32_t num_aggregators;
-    uint32_t mode;                    // 0: whisper's batched reports; 1: draft-07 VdafKey (prepare_init)
+    uint32_t mode;                    // 0: whisper's batched reports; 1: draft-07 VdafKey (prepare_init); 2: bare FLP query
+    uint32_t ver_stride;              // elements per row of the verifier output (verifier_len, + 1 with the joint-rand part)
     F128 half;                        // num_shares^-1 = 2^-1
     F128 m_inv;                       // m^-1
     F128 sampler_bound;               // p (test hook: a smaller bound makes the sampler's skip branch run)

@@ -40,6 +40,26 @@ def client_set_test_sampler_bound(bound=None):
     lib.wh_client_set_test_sampler_bound(None if b is None else b.ctypes.data)
 
 
+def flp_encode(params, measurement):
+    """Type::encode_measurement -> bytes(input_len*16)."""
+    m = np.ascontiguousarray(measurement, dtype=np.uint64)
+    out = np.zeros(16 * params.sizes.input_len, np.uint8)
+    rc = lib.wh_flp_encode(C.byref(params.c), m.ctypes.data, out.ctypes.data)
+    if rc:
+        raise WhError(rc, "flp_encode")
+    return out
+
+
+def flp_prove(params, inp, prove_rand, joint_rand):
+    """Type::prove (CPU) -> uint8[proof_len*16]."""
+    a = [np.ascontiguousarray(x, dtype=np.uint8) for x in (inp, prove_rand, joint_rand)]
+    out = np.zeros(16 * params.sizes.proof_len, np.uint8)
+    rc = lib.wh_flp_prove(C.byref(params.c), a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, out.ctypes.data)
+    if rc:
+        raise WhError(rc, "flp_prove")
+    return out
+
+
 def shard_batched_many(params, measurements, nonces, rands, first_client_id=0, nthreads=8):
     """CPU client: client-batch-prio3/src/main.rs:67-153 for n clients.
 
@@ -161,6 +181,26 @@ class Prio3:
         status = np.zeros(n, np.int32)
         self._chk(lib.wh_prio3_prepare_finish_batch(self._ctx, ptrs, n, msgs.ctypes.data, status.ctypes.data), "prepare_finish_batch")
         return msgs, status
+
+    # ---- flp::Type surface (flp.rs:186-196) ----
+    def flp_query(self, inputs, proofs, query_rands, joint_rands, num_shares):
+        """Type::query for n tuples: uint8 arrays [n, input_len*16], [n, proof_len*16], [n, 16], [n, jr_len*16].
+        Returns (verifiers [n, verifier_len*16], status [n])."""
+        a = [np.ascontiguousarray(x, dtype=np.uint8) for x in (inputs, proofs, query_rands, joint_rands)]
+        n = a[0].shape[0]
+        ver = np.zeros((n, 16 * self.sizes.verifier_len), np.uint8)
+        status = np.zeros(n, np.int32)
+        self._chk(lib.wh_flp_query_batch(self._ctx, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data,
+                                         num_shares, n, ver.ctypes.data, status.ctypes.data), "flp_query_batch")
+        self.n_last = n
+        return ver, status
+
+    def flp_decide(self, verifiers):
+        v = np.ascontiguousarray(verifiers, dtype=np.uint8)
+        n = v.shape[0]
+        out = np.zeros(n, np.int32)
+        self._chk(lib.wh_flp_decide_batch(self._ctx, v.ctypes.data, n, out.ctypes.data), "flp_decide_batch")
+        return out
 
     def out_shares(self):
         out = np.zeros((self.n_last, 16 * self.sizes.output_len), np.uint8)
