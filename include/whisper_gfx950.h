@@ -192,6 +192,9 @@ int32_t wh_client_shard_many(const wh_prio3_params *params, const uint64_t *meas
 /* ---- unit-parity surface (mirrors field.rs / xof.rs for kernel-level tests) ---- */
 /* op: 0 add, 1 sub, 2 mul, 3 inv(a).  Host buffers of n 16-byte elements. */
 int32_t wh_test_f128_op(wh_ctx *ctx, int32_t op, const uint8_t *a, const uint8_t *b, uint8_t *out, uint64_t n);
+/* Field64 (fp.rs:359-389), canonical u64 residues: op 0 add, 1 sub, 2 mul, 3 inv.  Arithmetic layer only: no server of
+ * the reference instantiates a Field64 type. */
+int32_t wh_test_f64_op(wh_ctx *ctx, int32_t op, const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t n);
 /* per seed i: XofShake128::seed_stream(seed_i, dst(alg_id, usage), binder).into_field_vec(n_elems) */
 int32_t wh_test_xof_expand(wh_ctx *ctx, const uint8_t *seeds, uint64_t n, uint32_t alg_id, uint32_t usage,
                            const uint8_t *binder, uint32_t binder_len, uint32_t n_elems, uint8_t *out);

@@ -52,6 +52,23 @@ def test_field_ops_bit_exact(small_ctx):
     assert out == b"".join(O.f_enc((2**32 - 1) * x % p) for x in a2)
 
 
+def test_field64_ops_bit_exact(small_ctx):
+    """Field64 = GF(2^64 - 2^32 + 1) (fp.rs:359-389): the device arithmetic against Python integers, with the
+    edge values of the Goldilocks reduction (multiples of 2^32 - 1, p - 1, values whose product wraps)."""
+    p = 2**64 - 2**32 + 1
+    assert p == 18446744069414584321      # fp.rs:360
+    rnd = np.random.default_rng(64)
+    edge = [0, 1, 2, p - 1, p - 2, 2**32 - 1, 2**32, 2**32 + 1, 2**63, p - 2**32, 0xffffffff, 0xfffffffe00000001, 7]
+    vals = edge + [int(x) % p for x in rnd.integers(0, 2**64, size=600, dtype=np.uint64)]
+    a = np.array([vals[i % len(vals)] for i in range(4096)], np.uint64)
+    b = np.array([vals[(i * 7 + i // len(vals)) % len(vals)] for i in range(4096)], np.uint64)
+    for op, fn in ((0, lambda x, y: (x + y) % p), (1, lambda x, y: (x - y) % p), (2, lambda x, y: x * y % p)):
+        out = small_ctx.test_f64_op(op, a, b)
+        assert [int(v) for v in out] == [fn(int(x), int(y)) for x, y in zip(a, b)], op
+    out = small_ctx.test_f64_op(3, a[:256])
+    assert [int(v) for v in out] == [pow(int(x), p - 2, p) for x in a[:256]]
+
+
 @pytest.mark.parametrize("n_elems,binder", [(1, b""), (2, b"\x01"), (10, b"x" * 16), (11, b""), (21, b"abc"), (22, b"q" * 143),
                                             (255, b"\x01"), (2048, b"\x01")])
 def test_xof_expand_bit_exact(small_ctx, n_elems, binder):

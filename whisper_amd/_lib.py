@@ -40,7 +40,7 @@ EXPORTS = [
     "wh_ctx_synchronize", "wh_client_shard_batched", "wh_client_shard_many", "wh_test_f128_op",
     "wh_test_xof_expand", "wh_ctx_set_profiling", "wh_ctx_kernel_times",
     "wh_ctx_set_test_sampler_bound", "wh_client_set_test_sampler_bound",
-    "wh_flp_query_batch", "wh_flp_decide_batch", "wh_flp_encode", "wh_flp_prove", "wh_hh_bucket_accumulate_u32_dev", "wh_prio3_prepare_init_batch_dev", "wh_prio3_prepare_init_batch", "wh_prio3_prepare_finish_batch",
+    "wh_test_f64_op", "wh_flp_query_batch", "wh_flp_decide_batch", "wh_flp_encode", "wh_flp_prove", "wh_hh_bucket_accumulate_u32_dev", "wh_prio3_prepare_init_batch_dev", "wh_prio3_prepare_init_batch", "wh_prio3_prepare_finish_batch",
 ]
 
 vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32
@@ -70,6 +70,7 @@ lib.wh_test_xof_expand.argtypes = [vp, vp, u64, u32, u32, vp, u32, u32, vp]
 lib.wh_prio3_prepare_init_batch_dev.argtypes = [vp, vp, vp, vp, u64, vp, vp]
 lib.wh_prio3_prepare_init_batch.argtypes = [vp, vp, vp, vp, u64, vp, vp]
 lib.wh_prio3_prepare_finish_batch.argtypes = [vp, vp, u64, vp, vp]
+lib.wh_test_f64_op.argtypes = [vp, i32, vp, vp, vp, u64]
 lib.wh_flp_query_batch.argtypes = [vp, vp, vp, vp, vp, u32, u64, vp, vp]
 lib.wh_flp_decide_batch.argtypes = [vp, vp, u64, vp]
 lib.wh_flp_encode.argtypes = [C.POINTER(Params), vp, vp]

@@ -666,6 +666,20 @@ int32_t wh_test_f128_op(wh_ctx *c, int32_t op, const uint8_t *a, const uint8_t *
     return WH_OK;
 }
 
+int32_t wh_test_f64_op(wh_ctx *c, int32_t op, const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t n) {
+    if (!c || !a || !out || !n) return WH_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint64_t *da, *db, *dout;
+    HIPCHK(c, hipMalloc((void **)&da, 8 * n)); HIPCHK(c, hipMalloc((void **)&db, 8 * n)); HIPCHK(c, hipMalloc((void **)&dout, 8 * n));
+    HIPCHK(c, hipMemcpy(da, a, 8 * n, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(db, b ? b : a, 8 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_test_f64, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, da, db, dout, (uint32_t)n, op);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, dout, 8 * n, hipMemcpyDeviceToHost));
+    hipFree(da); hipFree(db); hipFree(dout);
+    return WH_OK;
+}
+
 int32_t wh_test_xof_expand(wh_ctx *c, const uint8_t *seeds, uint64_t n, uint32_t alg_id, uint32_t usage, const uint8_t *binder,
                            uint32_t binder_len, uint32_t n_elems, uint8_t *out) {
     if (!c || !seeds || !out || !n || !n_elems) return WH_ERR_PARAM;

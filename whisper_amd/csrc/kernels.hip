@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include "keccak.hpp"
 #include "prio3_dev.hpp"
+#include "f64.hpp"
 
 namespace wh {
 
@@ -1077,6 +1078,12 @@ __global__ void k_test_f128(const F128 *a, const F128 *b, F128 *out, uint32_t n,
     }
     }
     out[i] = r;
+}
+// Field64 (f64.hpp): op 0 add, 1 sub, 2 mul, 3 inv
+__global__ void k_test_f64(const uint64_t *a, const uint64_t *b, uint64_t *out, uint32_t n, int op) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = op == 0 ? g_add(a[i], b[i]) : op == 1 ? g_sub(a[i], b[i]) : op == 2 ? g_mul(a[i], b[i]) : g_inv(a[i]);
 }
 // XofShake128::seed_stream(seed, dst(alg_id, usage), binder).into_field_vec(n) per lane
 __global__ void __launch_bounds__(64) k_test_xof(const uint8_t *seeds, uint32_t alg_id, uint32_t usage, const uint8_t *binder,

@@ -263,6 +263,13 @@ class Prio3:
         self._chk(lib.wh_test_f128_op(self._ctx, op, a.ctypes.data, bp, out.ctypes.data, n), "test_f128_op")
         return out
 
+    def test_f64_op(self, op, a, b=None):
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        bb = None if b is None else np.ascontiguousarray(b, dtype=np.uint64)
+        out = np.zeros_like(a)
+        self._chk(lib.wh_test_f64_op(self._ctx, op, a.ctypes.data, _ptr(bb), out.ctypes.data, a.size), "test_f64_op")
+        return out
+
     def test_xof_expand(self, seeds, alg_id, usage, binder, n_elems):
         seeds = np.ascontiguousarray(seeds, dtype=np.uint8)
         n = seeds.size // 16
