@@ -59,6 +59,8 @@ enum {
     WH_ERR_QUERY_RAND = -6,   /* FlpError::Query: r is an m-th root of unity (flp.rs:413-419) */
     WH_ERR_DECIDE = -7,       /* "proof verifier check failed" (prio3.rs:2372-2378) */
     WH_ERR_JOINT_RAND = -8,   /* "joint randomness mismatch" (prio3.rs:2414-2420) */
+    WH_ERR_KEY_FORMAT = -9,   /* heavy-hitter key chain: bincode would fail on it, or a length disagrees with the configured
+                               * shape (index panic in eval_all, assert at hhcore/src/protocol.rs:95) */
     /* library-level */
     WH_ERR_HIP = -100,
     WH_ERR_NO_DEVICE = -101,
@@ -163,6 +165,34 @@ int32_t wh_hh_bucket_sum_u32_dev(wh_ctx *ctx, const uint32_t *d_buckets, const u
 int32_t wh_hh_bucket_accumulate_u32_dev(wh_ctx *ctx, const uint32_t *d_buckets, const uint8_t *d_keep, uint64_t n,
                                         uint64_t words, uint32_t *d_acc);
 
+/* replaces: the expansion loop of server-hh (server-hh/src/main.rs:163-174, 255-265) =
+ *   Prf::compute_prf(key.id.to_le_bytes()) + BCSketch::eval_and_check::<IntModN<NumBuckets>> (hhcore/src/protocol.rs:78-176)
+ *   = VDPFKey::eval_all of the main key and of the 257 support keys (hhcore/src/vdpf.rs:123-214; PRG and MMO hashes
+ *   common/src/prg.rs:133-241, 280-475, 599-631), consistency folding and the SHA-256 proof string.
+ * keys: n key chains, `stride` bytes apart, each the bincode 1.3.3 bytes of a KeyChain<u32> exactly as the servers receive
+ * them (serialize/src/lib.rs:72-80): wh_hh_key_chain_len(depth) bytes, num_buckets = 2^depth, depth 1..11.
+ *   dat         n * 2^depth * 258 u32   Vec<Bucket<u32>> per key chain (256 data, sign_data, ctr); NULL keeps it in the context
+ *   tags        n * 64                  the proof `String`: 64 lower-case hex characters
+ *   testing_ids n * 16                  u128 LE
+ *   status      n                       WH_ERR_KEY_FORMAT where the reference would abort; such a key chain gets a zero tag and
+ *                                       an all-zero bucket vector
+ * The caller sorts by testing id and runs general_binary_split_test over the tags, as server-hh does. */
+uint64_t wh_hh_key_chain_len(uint32_t depth);
+/* a context for a server that runs only the heavy-hitter path (no Prio3 instance to describe) */
+int32_t wh_hh_ctx_create(int32_t device_id, wh_ctx **out);
+int32_t wh_hh_eval_and_check_batch_dev(wh_ctx *ctx, const uint8_t verify_key[16], const uint8_t *d_keys, uint64_t stride, uint64_t n,
+                                       uint32_t depth, uint32_t *d_dat, uint8_t *d_tags, uint8_t *d_testing_ids, int32_t *d_status);
+/* Same with HOST buffers; the bucket vectors stay in the context for wh_hh_aggregate* / wh_hh_buckets. */
+int32_t wh_hh_eval_and_check_batch(wh_ctx *ctx, const uint8_t verify_key[16], const uint8_t *keys, uint64_t stride, uint64_t n,
+                                   uint32_t depth, uint8_t *tags, uint8_t *testing_ids, int32_t *status);
+/* eval_and_check's first return value for the last batch, copied to the host (n * 2^depth * 258 u32) */
+int32_t wh_hh_buckets(wh_ctx *ctx, uint32_t *dat);
+/* replaces: aggregate_hhs' reduce over the last batch's bucket vectors (server-hh/src/main.rs:72-104): keep[n] 1 = add,
+ * 0 = skip (NULL = all); acc = 2^depth * 258 u32.  The _dev form adds into d_acc when `accumulate` is non-zero
+ * (CountSketch::insert in the streaming server, main.rs:192-197). */
+int32_t wh_hh_aggregate(wh_ctx *ctx, const uint8_t *keep, uint32_t *acc);
+int32_t wh_hh_aggregate_dev(wh_ctx *ctx, const uint8_t *d_keep, uint32_t *d_acc, int32_t accumulate);
+
 int32_t wh_ctx_synchronize(wh_ctx *ctx);
 
 /* ---- measurement ---- */
@@ -170,7 +200,7 @@ int32_t wh_ctx_synchronize(wh_ctx *ctx);
  * 276,340-341,414-421).  With profiling on, every kernel launch is bracketed by HIP events on
  * the context stream; wh_ctx_kernel_times synchronises and returns accumulated milliseconds and
  * launch counts per kernel (indices WH_K_*), optionally resetting them. */
-enum { WH_K_PARSE = 0, WH_K_EXPAND = 1, WH_K_HASH = 2, WH_K_QUERY = 3, WH_K_AGG = 4, WH_K_HH = 5, WH_K_MEAS = 6, WH_NUM_KERNELS = 7 };
+enum { WH_K_PARSE = 0, WH_K_EXPAND = 1, WH_K_HASH = 2, WH_K_QUERY = 3, WH_K_AGG = 4, WH_K_HH = 5, WH_K_MEAS = 6, WH_K_HH_EVAL = 7, WH_NUM_KERNELS = 8 };
 int32_t wh_ctx_set_profiling(wh_ctx *ctx, int32_t on);
 int32_t wh_ctx_kernel_times(wh_ctx *ctx, double *ms, uint64_t *launches, int32_t reset);
 
@@ -188,6 +218,12 @@ int32_t wh_client_shard_batched(const wh_prio3_params *params, const uint64_t *m
 int32_t wh_client_shard_many(const wh_prio3_params *params, const uint64_t *measurements, uint32_t meas_words,
                              const uint8_t *nonces, const uint8_t *rands, uint64_t first_client_id, uint64_t n,
                              uint32_t nthreads, uint8_t *leader_reports, uint8_t *helper_reports);
+
+/* replaces (CPU, client side): BCSketch::gen_key_chain (hhcore/src/protocol.rs:31-76) for IntModN<2^depth> -- VDPFKey::gen
+ * (hhcore/src/vdpf.rs:54-113) of the main key and of the 257 support keys -- and bincode serialisation.  bucket: 256 data
+ * + sign_data (each 1 or -1 mod 2^32) + ctr; thread_rng is replaced by SHAKE128(rng_seed).  Writes both servers' key chains. */
+int32_t wh_hh_gen_key_chain(uint32_t depth, const uint8_t id_le[16], uint32_t alpha, const uint32_t bucket[258],
+                            const uint8_t rng_seed[32], uint8_t *key_chain_0, uint8_t *key_chain_1);
 
 /* ---- unit-parity surface (mirrors field.rs / xof.rs for kernel-level tests) ---- */
 /* op: 0 add, 1 sub, 2 mul, 3 inv(a).  Host buffers of n 16-byte elements. */

@@ -60,7 +60,8 @@ enum {
     WO_ERR_MODULUS = -3,      /* FieldError::ModulusOverflow while decoding */
     WO_ERR_AGG_ID = -4,       /* role_try_from: unexpected aggregator id */
     WO_ERR_NUM_QUERIES = -5,  /* assert_eq!(public_proof.len, verifier.len) would panic */
-    WO_ERR_QUERY_RAND = -6    /* FlpError::Query: query randomness is a root of unity */
+    WO_ERR_QUERY_RAND = -6,   /* FlpError::Query: query randomness is a root of unity */
+    WO_ERR_KEY_FORMAT = -9    /* heavy-hitter key chain: bincode would fail, or a length disagrees with the shape */
 };
 
 int wo_sizes_of(const wo_params *p, wo_sizes *out);
@@ -138,6 +139,25 @@ void wo_aes128_encrypt_block(const uint8_t key[16], const uint8_t in[16], uint8_
 /* heavy hitters: sum of kept clients' bucket vectors, u32 wrapping (bucket.rs:48-55) */
 void wo_hh_bucket_sum_u32(const uint32_t *buckets, const uint8_t *keep, uint64_t n,
                           uint64_t words, uint32_t *acc);
+
+
+/* ---- heavy-hitter key chains (hhcore/src/{vdpf,dpf,protocol}.rs, common/src/prg.rs); see vdpf.c ---- */
+/* bytes of one bincode-encoded KeyChain<u32> whose main key has `depth` levels (num_buckets = 2^depth) */
+uint64_t wo_hh_key_chain_len(uint32_t depth);
+/* gen_key_chain (protocol.rs:31-76) for IntModN<2^depth>; bucket = 256 data + sign_data + ctr, entries +-1;
+ * thread_rng is replaced by SHAKE128(rng_seed).  Writes both servers' encoded key chains. */
+int wo_hh_gen_key_chain(uint32_t depth, const uint8_t id_le[16], uint32_t alpha, const uint32_t bucket[258],
+                        const uint8_t rng_seed[32], uint8_t *kc0, uint8_t *kc1);
+/* eval_and_check (protocol.rs:78-176): dat[2^depth][258] (may be NULL), tag = 64 lower-case hex characters */
+int wo_hh_eval_and_check(uint32_t depth, const uint8_t *kc, uint64_t kc_len, uint32_t *dat, uint8_t tag_hex[64]);
+/* the per-key loop of server-hh (main.rs:255-265) with the PRF testing id, `nthreads` host threads */
+int wo_hh_eval_and_check_batch(uint32_t depth, const uint8_t verify_key[16], const uint8_t *keys, uint64_t stride,
+                               uint64_t n, unsigned nthreads, uint32_t *dat, uint8_t *tags_hex, uint8_t *testing_ids,
+                               int32_t *status);
+void wo_sha256(const uint8_t *in, size_t n, uint8_t out[32]);
+/* AES_k(in) ^ in under the fixed key [key_byte; 16] (key_byte 0: FixedKeyPrgStream, 1: HasherStream) */
+void wo_mmo_fixed(int key_byte, const uint8_t in[16], uint8_t out[16]);
+int wo_aes_backend(void); /* 1 = AES-NI, 0 = portable */
 
 #ifdef __cplusplus
 }

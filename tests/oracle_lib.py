@@ -228,3 +228,65 @@ def hh_bucket_sum_u32(buckets, keep=None):
     _lib.wo_hh_bucket_sum_u32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
     _lib.wo_hh_bucket_sum_u32(buckets.ctypes.data, keep_p, n, words, acc.ctypes.data)
     return acc.reshape(buckets.shape[1:])
+
+
+# ---- heavy-hitter key chains (oracle/vdpf.c) ----
+ERR_KEY_FORMAT = -9
+BUCKET_WORDS = 258
+
+
+def sha256(data):
+    o = _buf(32); _lib.wo_sha256(_b(data) if data else None, C.c_size_t(len(data)), o); return bytes(o)
+
+
+def mmo_fixed(key_byte, block):
+    o = _buf(16); _lib.wo_mmo_fixed(C.c_int(key_byte), _b(block), o); return bytes(o)
+
+
+def aes_backend():
+    return int(_lib.wo_aes_backend())
+
+
+_lib.wo_hh_key_chain_len.restype = C.c_uint64
+
+
+def hh_key_chain_len(depth):
+    return int(_lib.wo_hh_key_chain_len(C.c_uint32(depth)))
+
+
+def hh_gen_key_chain(depth, client_id, alpha, bucket, rng_seed):
+    """bucket: 258 u32 (256 data, sign_data, ctr).  Returns the two servers' bincode key chains."""
+    n = hh_key_chain_len(depth)
+    k0, k1 = _buf(n), _buf(n)
+    bk = np.ascontiguousarray(bucket, dtype=np.uint32)
+    assert bk.shape == (BUCKET_WORDS,)
+    _lib.wo_hh_gen_key_chain.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = _lib.wo_hh_gen_key_chain(depth, C.cast(_b(int(client_id).to_bytes(16, "little")), C.c_void_p), alpha,
+                                  bk.ctypes.data, C.cast(_b(rng_seed), C.c_void_p), C.cast(k0, C.c_void_p), C.cast(k1, C.c_void_p))
+    if rc:
+        raise ValueError(f"gen_key_chain rc={rc}")
+    return bytes(k0), bytes(k1)
+
+
+def hh_eval_and_check(depth, key_chain, want_dat=True):
+    dat = np.zeros(((1 << depth), BUCKET_WORDS), np.uint32) if want_dat else None
+    tag = _buf(64)
+    _lib.wo_hh_eval_and_check.argtypes = [C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    rc = _lib.wo_hh_eval_and_check(depth, C.cast(_b(key_chain), C.c_void_p), len(key_chain),
+                                   dat.ctypes.data if want_dat else None, C.cast(tag, C.c_void_p))
+    return rc, dat, bytes(tag)
+
+
+def hh_eval_and_check_batch(depth, verify_key, keys, nthreads=1, want_dat=True):
+    """keys: np.uint8 [n, stride].  Returns (dat[n, 2^depth, 258] or None, tags[n, 64], ids[n, 16], status[n])."""
+    keys = np.ascontiguousarray(keys, dtype=np.uint8)
+    n, stride = keys.shape
+    dat = np.zeros((n, 1 << depth, BUCKET_WORDS), np.uint32) if want_dat else None
+    tags = np.zeros((n, 64), np.uint8); ids = np.zeros((n, 16), np.uint8); status = np.zeros(n, np.int32)
+    _lib.wo_hh_eval_and_check_batch.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = _lib.wo_hh_eval_and_check_batch(depth, C.cast(_b(verify_key), C.c_void_p), keys.ctypes.data, stride, n, nthreads,
+                                         dat.ctypes.data if want_dat else None, tags.ctypes.data, ids.ctypes.data,
+                                         status.ctypes.data)
+    assert rc == 0, rc
+    return dat, tags, ids, status

@@ -11,3 +11,4 @@ from .prio3 import (  # noqa: F401
     client_set_test_sampler_bound, flp_encode, flp_prove, SUMVEC, HISTOGRAM, AVERAGE,
 )
 from .grouptest import general_binary_split_test, ClientProofTag  # noqa: F401
+from . import hh  # noqa: F401,E402

@@ -41,6 +41,8 @@ EXPORTS = [
     "wh_test_xof_expand", "wh_ctx_set_profiling", "wh_ctx_kernel_times",
     "wh_ctx_set_test_sampler_bound", "wh_client_set_test_sampler_bound",
     "wh_test_f64_op", "wh_flp_query_batch", "wh_flp_decide_batch", "wh_flp_encode", "wh_flp_prove", "wh_hh_bucket_accumulate_u32_dev", "wh_prio3_prepare_init_batch_dev", "wh_prio3_prepare_init_batch", "wh_prio3_prepare_finish_batch",
+    "wh_hh_key_chain_len", "wh_hh_ctx_create", "wh_hh_eval_and_check_batch_dev", "wh_hh_eval_and_check_batch", "wh_hh_buckets",
+    "wh_hh_aggregate", "wh_hh_aggregate_dev", "wh_hh_gen_key_chain",
 ]
 
 vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32
@@ -78,7 +80,16 @@ lib.wh_flp_prove.argtypes = [C.POINTER(Params), vp, vp, vp, vp]
 lib.wh_ctx_set_test_sampler_bound.argtypes = [vp, vp]
 lib.wh_client_set_test_sampler_bound.argtypes = [vp]
 lib.wh_client_set_test_sampler_bound.restype = None
+lib.wh_hh_key_chain_len.argtypes = [u32]
+lib.wh_hh_ctx_create.argtypes = [i32, C.POINTER(vp)]
+lib.wh_hh_eval_and_check_batch_dev.argtypes = [vp, vp, vp, u64, u64, u32, vp, vp, vp, vp]
+lib.wh_hh_eval_and_check_batch.argtypes = [vp, vp, vp, u64, u64, u32, vp, vp, vp]
+lib.wh_hh_buckets.argtypes = [vp, vp]
+lib.wh_hh_aggregate.argtypes = [vp, vp, vp]
+lib.wh_hh_aggregate_dev.argtypes = [vp, vp, vp, i32]
+lib.wh_hh_gen_key_chain.argtypes = [u32, vp, u32, vp, vp, vp, vp]
 for _n in EXPORTS:
     getattr(lib, _n)  # AttributeError here = the library does not export what the header declares
     if _n not in ("wh_ctx_destroy", "wh_last_error", "wh_ctx_stream", "wh_client_set_test_sampler_bound"):
         getattr(lib, _n).restype = i32
+lib.wh_hh_key_chain_len.restype = u64

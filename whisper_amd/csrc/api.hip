@@ -7,6 +7,8 @@
 #include <string>
 #include <vector>
 #include "host_math.hpp"
+#include "aes_host.hpp"
+#include "hh_dev.hpp"
 #include "kernels.hip"
 
 using namespace wh;
@@ -49,6 +51,17 @@ struct wh_ctx {
     struct Ev { hipEvent_t a, b; int id; };
     std::vector<Ev> evs;
     std::vector<hipEvent_t> ev_pool;
+    // heavy-hitter key chains (vdpf.hip)
+    HhTables *d_hh_tab = nullptr; bool hh_tab_valid = false; uint8_t hh_vk[16] = {0};
+    HhWork hh_w{}; uint64_t hh_cap = 0; uint32_t hh_cap_depth = 0;
+    uint32_t *d_hh_dat = nullptr; uint64_t hh_dat_cap = 0;      // [n][2^depth][258] of the last batch, when the caller gave no buffer
+    const uint32_t *d_hh_dat_last = nullptr; uint64_t hh_n_last = 0; uint32_t hh_depth_last = 0;
+    uint8_t *d_hh_keys = nullptr; uint64_t hh_keys_cap = 0;
+    uint8_t *d_hh_tags = nullptr; uint64_t hh_tags_cap = 0;
+    uint8_t *d_hh_ids = nullptr; uint64_t hh_ids_cap = 0;
+    int32_t *d_hh_status = nullptr; uint64_t hh_status_cap = 0;
+    uint8_t *d_hh_keep = nullptr; uint64_t hh_keep_cap = 0;
+    uint32_t *d_hh_acc = nullptr; uint64_t hh_acc_cap = 0;
     double k_ms[WH_NUM_KERNELS] = {0};
     uint64_t k_launches[WH_NUM_KERNELS] = {0};
     std::string err;
@@ -251,7 +264,9 @@ void wh_ctx_destroy(wh_ctx *c) {
     if (c->stream2) hipStreamSynchronize(c->stream2);
     void *ptrs[] = {c->d_omega, c->d_stab, c->d_aes, c->d_out_shares, c->d_status_own, c->d_keep_eff, c->d_partials,
                     c->d_blob, c->d_offsets, c->d_tags, c->d_ids, c->d_prep, c->W.desc, c->W.scal, c->W.weights, c->W.wlimbs, c->W.pows, c->W.rlc,
-                    c->W.hrows, c->W.hlist, c->W.llist, c->W.dirty, c->W.counters};
+                    c->W.hrows, c->W.hlist, c->W.llist, c->W.dirty, c->W.counters,
+                    c->d_hh_tab, c->hh_w.tpc, c->hh_w.proofblk, c->hh_w.supd, c->hh_w.buckg, c->d_hh_dat, c->d_hh_keys, c->d_hh_tags,
+                    c->d_hh_ids, c->d_hh_status, c->d_hh_keep, c->d_hh_acc};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
@@ -615,6 +630,137 @@ int32_t wh_hh_bucket_sum_u32_dev(wh_ctx *c, const uint32_t *d_buckets, const uin
 int32_t wh_hh_bucket_accumulate_u32_dev(wh_ctx *c, const uint32_t *d_buckets, const uint8_t *d_keep, uint64_t n, uint64_t words,
                                         uint32_t *d_acc) {
     return hh_sum(c, d_buckets, d_keep, n, words, d_acc, false);
+}
+
+// ---- heavy-hitter key chains ----
+int32_t wh_hh_ctx_create(int32_t device_id, wh_ctx **out) {
+    // the heavy-hitter entry points use the context's device, stream and buffers only; the Prio3 tables are those of
+    // the smallest circuit
+    const wh_prio3_params p = {WH_HISTOGRAM, 0, 2, 1, 2, 0};
+    return wh_ctx_create(device_id, &p, out);
+}
+uint64_t wh_hh_key_chain_len(uint32_t depth) { return depth >= 1 && depth <= HH_MAX_DEPTH ? HhLayout(depth).total : 0; }
+
+static int32_t hh_tables(wh_ctx *c, const uint8_t verify_key[16]) {
+    if (c->hh_tab_valid && !memcmp(c->hh_vk, verify_key, 16)) return WH_OK;
+    if (!c->d_hh_tab) HIPCHK(c, hipMalloc((void **)&c->d_hh_tab, sizeof(HhTables)));
+    HhTables t;
+    memcpy(t.te0, aes_tables_host().te0, sizeof t.te0);
+    uint8_t k[16];
+    memset(k, 0, 16); const AesKey k0(k);
+    memset(k, 1, 16); const AesKey k1(k);
+    const AesKey kv(verify_key);
+    memcpy(t.rk[0], k0.rk, sizeof k0.rk); memcpy(t.rk[1], k1.rk, sizeof k1.rk); memcpy(t.rk[2], kv.rk, sizeof kv.rk);
+    for (int x = 0; x < 2; x++) {
+        uint8_t b[16] = {0}, s0[16], s2[16];
+        b[0] = (uint8_t)x;
+        k0.mmo(b, s0); k0.mmo(s0, s2);
+        memcpy(&t.cx[x][0], s0, 16); memcpy(&t.cx[x][4], s2, 16);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_hh_tab, &t, sizeof t, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(c->hh_vk, verify_key, 16);
+    c->hh_tab_valid = true;
+    return WH_OK;
+}
+
+static int32_t hh_workspace(wh_ctx *c, uint64_t cap, uint32_t depth) {
+    if (cap <= c->hh_cap && depth <= c->hh_cap_depth) return WH_OK;
+    if (cap < c->hh_cap) cap = c->hh_cap;
+    if (depth < c->hh_cap_depth) depth = c->hh_cap_depth;
+    void *ptrs[] = {c->hh_w.tpc, c->hh_w.proofblk, c->hh_w.supd, c->hh_w.buckg};
+    for (void *p : ptrs) if (p) HIPCHK(c, hipFree(p));
+    c->hh_w = HhWork{}; c->hh_cap = 0; c->hh_cap_depth = 0;
+    HIPCHK(c, hipMalloc((void **)&c->hh_w.tpc, cap * (64ull << depth)));
+    HIPCHK(c, hipMalloc((void **)&c->hh_w.proofblk, cap * (HH_SUPPORT + 1) * 64ull));
+    HIPCHK(c, hipMalloc((void **)&c->hh_w.supd, cap * HH_SUPPORT * 8ull));
+    HIPCHK(c, hipMalloc((void **)&c->hh_w.buckg, cap * HH_BKT * 4ull));
+    c->hh_cap = cap; c->hh_cap_depth = depth;
+    return WH_OK;
+}
+
+int32_t wh_hh_eval_and_check_batch_dev(wh_ctx *c, const uint8_t verify_key[16], const uint8_t *d_keys, uint64_t stride, uint64_t n,
+                                       uint32_t depth, uint32_t *d_dat, uint8_t *d_tags, uint8_t *d_ids, int32_t *d_status) {
+    if (!c || !verify_key || depth < 1 || depth > HH_MAX_DEPTH || (n && (!d_keys || !d_tags || !d_ids || !d_status))) return WH_ERR_PARAM;
+    if (stride < HhLayout(depth).total || n > 0x7fffffffull) return WH_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    int32_t rc;
+    if ((rc = hh_tables(c, verify_key))) return rc;
+    const uint64_t words = (uint64_t)HH_BKT << depth;
+    if (!d_dat) {
+        if ((rc = ensure(c, c->d_hh_dat, c->hh_dat_cap, (n ? n : 1) * words))) return rc;
+        d_dat = c->d_hh_dat;
+    }
+    // sub-batches bound the scratch (64 B per leaf for the proof chain): at most 16384 key chains or 2 GiB at a time
+    uint64_t cap = (2ull << 30) / (64ull << depth);
+    if (cap > 16384) cap = 16384;
+    if (cap > n) cap = n ? n : 1;
+    if ((rc = hh_workspace(c, cap, depth))) return rc;
+    c->d_hh_dat_last = d_dat; c->hh_n_last = n; c->hh_depth_last = depth;
+    for (uint64_t base = 0; base < n; base += cap) {
+        const uint32_t m = (uint32_t)(n - base < cap ? n - base : cap);
+        KTimer t_(c, WH_K_HH_EVAL);
+        const int e = launch_hh_eval(d_keys + base * stride, stride, m, depth, c->d_hh_tab, c->hh_w, d_dat + base * words,
+                                     d_tags + 64 * base, d_ids + 16 * base, d_status + base, c->stream);
+        if (e) { c->err = std::string("heavy-hitter eval launch: ") + hipGetErrorString((hipError_t)e); return WH_ERR_HIP; }
+    }
+    return WH_OK;
+}
+
+int32_t wh_hh_eval_and_check_batch(wh_ctx *c, const uint8_t verify_key[16], const uint8_t *keys, uint64_t stride, uint64_t n,
+                                   uint32_t depth, uint8_t *tags, uint8_t *testing_ids, int32_t *status) {
+    if (!c || !verify_key || (n && (!keys || !tags || !testing_ids || !status))) return WH_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    int32_t rc;
+    const uint64_t m = n ? n : 1;
+    if ((rc = ensure(c, c->d_hh_keys, c->hh_keys_cap, m * stride))) return rc;
+    if ((rc = ensure(c, c->d_hh_tags, c->hh_tags_cap, m * 64))) return rc;
+    if ((rc = ensure(c, c->d_hh_ids, c->hh_ids_cap, m * 16))) return rc;
+    if ((rc = ensure(c, c->d_hh_status, c->hh_status_cap, m))) return rc;
+    if (n) HIPCHK(c, hipMemcpyAsync(c->d_hh_keys, keys, n * stride, hipMemcpyHostToDevice, c->stream));
+    if ((rc = wh_hh_eval_and_check_batch_dev(c, verify_key, c->d_hh_keys, stride, n, depth, nullptr, c->d_hh_tags, c->d_hh_ids,
+                                             c->d_hh_status))) return rc;
+    if (n) {
+        HIPCHK(c, hipMemcpyAsync(tags, c->d_hh_tags, n * 64, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(testing_ids, c->d_hh_ids, n * 16, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(status, c->d_hh_status, n * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return WH_OK;
+}
+
+int32_t wh_hh_buckets(wh_ctx *c, uint32_t *dat) {
+    if (!c || !dat) return WH_ERR_PARAM;
+    if (!c->d_hh_dat_last) return WH_ERR_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dat, c->d_hh_dat_last, c->hh_n_last * ((uint64_t)HH_BKT << c->hh_depth_last) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return WH_OK;
+}
+
+int32_t wh_hh_aggregate_dev(wh_ctx *c, const uint8_t *d_keep, uint32_t *d_acc, int32_t accumulate) {
+    if (!c || !d_acc) return WH_ERR_PARAM;
+    if (!c->d_hh_dat_last) return WH_ERR_STATE;
+    return hh_sum(c, c->d_hh_dat_last, d_keep, c->hh_n_last, (uint64_t)HH_BKT << c->hh_depth_last, d_acc, !accumulate);
+}
+
+int32_t wh_hh_aggregate(wh_ctx *c, const uint8_t *keep, uint32_t *acc) {
+    if (!c || !acc) return WH_ERR_PARAM;
+    if (!c->d_hh_dat_last) return WH_ERR_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t n = c->hh_n_last, words = (uint64_t)HH_BKT << c->hh_depth_last;
+    int32_t rc;
+    if ((rc = ensure(c, c->d_hh_acc, c->hh_acc_cap, words))) return rc;
+    const uint8_t *d_keep = nullptr;
+    if (keep && n) {
+        if ((rc = ensure(c, c->d_hh_keep, c->hh_keep_cap, n))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->d_hh_keep, keep, n, hipMemcpyHostToDevice, c->stream));
+        d_keep = c->d_hh_keep;
+    }
+    if ((rc = wh_hh_aggregate_dev(c, d_keep, c->d_hh_acc, 0))) return rc;
+    HIPCHK(c, hipMemcpyAsync(acc, c->d_hh_acc, words * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return WH_OK;
 }
 
 int32_t wh_ctx_set_profiling(wh_ctx *c, int32_t on) {

@@ -1,0 +1,497 @@
+// Heavy-hitter key chains on gfx950: BCSketch::eval_and_check (hhcore/src/protocol.rs:78-176) for a batch of
+// bincode-encoded KeyChain<u32>, i.e. VDPFKey::eval_all (hhcore/src/vdpf.rs:123-214) of the main key and of the
+// 257 one-level support keys, the consistency folding, and the SHA-256 proof string.
+//
+//   k_hh_main     one workgroup per key chain: tree expansion (PrgSeed::expand_direction, common/src/prg.rs:133-174),
+//                 leaf hashes (mmo_hash2to4, :202-241), leaf conversion into Bucket<u32> (convert -> refill8,
+//                 :180-198, 368-403) written to `dat`, the per-position sum over all leaves, the PRF testing id
+//   k_hh_support  one lane per support key
+//   k_hh_chain    one lane per key chain: pi <- pi ^ H'(pi ^ corrected leaf hash), leaf by leaf (vdpf.rs:197-200;
+//                 mmo_hash4to4, prg.rs:599-631), then SHA-256
+//   k_hh_final    one lane per key chain: folding, the two vector digests and the digest of the 16640-character
+//                 proof string (protocol.rs:121-175)
+//
+// AES-128 has no instruction on CDNA4: one 256-entry table (Te0) sits in LDS 32 times over, word index
+// entry*32 + (lane & 31), so that the 32 lanes of a ds_read_b32 group always hit 32 different banks; the other
+// three tables are rotations.  160 table reads + 16 for the last round per block: the kernels are bound by LDS
+// reads (128 B/clk/CU), not by HBM.
+#include "hh_dev.hpp"
+
+namespace wh {
+namespace {
+
+constexpr int32_t HH_ERR_KEY_FORMAT = -9;  // WH_ERR_KEY_FORMAT
+constexpr uint32_t T_WORDS = 256 * 32;
+constexpr uint32_t HDR_BYTES = 1472;       // header of a key chain up to the support keys, depth <= 11
+
+struct B128 { uint32_t w[4]; };
+
+__device__ __forceinline__ uint32_t rotl(uint32_t v, int n) { return __builtin_rotateleft32(v, n); }
+
+// T points at this lane's copy of entry 0; rk = 44 round-key words (uniform)
+__device__ __forceinline__ B128 aes_enc(const uint32_t *T, const uint32_t *__restrict__ rk, const B128 &in) {
+    uint32_t s0 = in.w[0] ^ rk[0], s1 = in.w[1] ^ rk[1], s2 = in.w[2] ^ rk[2], s3 = in.w[3] ^ rk[3];
+#define TE(x, sh) T[(((x) >> (sh)) & 0xff) << 5]
+#pragma unroll
+    for (int r = 1; r < 10; r++) {
+        const uint32_t t0 = TE(s0, 0) ^ rotl(TE(s1, 8), 8) ^ rotl(TE(s2, 16), 16) ^ rotl(TE(s3, 24), 24) ^ rk[4 * r];
+        const uint32_t t1 = TE(s1, 0) ^ rotl(TE(s2, 8), 8) ^ rotl(TE(s3, 16), 16) ^ rotl(TE(s0, 24), 24) ^ rk[4 * r + 1];
+        const uint32_t t2 = TE(s2, 0) ^ rotl(TE(s3, 8), 8) ^ rotl(TE(s0, 16), 16) ^ rotl(TE(s1, 24), 24) ^ rk[4 * r + 2];
+        const uint32_t t3 = TE(s3, 0) ^ rotl(TE(s0, 8), 8) ^ rotl(TE(s1, 16), 16) ^ rotl(TE(s2, 24), 24) ^ rk[4 * r + 3];
+        s0 = t0; s1 = t1; s2 = t2; s3 = t3;
+    }
+    // last round: SubBytes + ShiftRows only; S[x] is byte 1 (and 2) of Te0[x]
+#define LAST(a, b, c, d) (((TE(a, 0) >> 8) & 0xff) | (TE(b, 8) & 0xff00) | (TE(c, 16) & 0xff0000) | ((TE(d, 24) << 8) & 0xff000000))
+    B128 o;
+    o.w[0] = LAST(s0, s1, s2, s3) ^ rk[40];
+    o.w[1] = LAST(s1, s2, s3, s0) ^ rk[41];
+    o.w[2] = LAST(s2, s3, s0, s1) ^ rk[42];
+    o.w[3] = LAST(s3, s0, s1, s2) ^ rk[43];
+#undef LAST
+#undef TE
+    return o;
+}
+// Matyas-Meyer-Oseas (prg.rs:311-331)
+__device__ __forceinline__ B128 mmo(const uint32_t *T, const uint32_t *__restrict__ rk, const B128 &in) {
+    B128 o = aes_enc(T, rk, in);
+    o.w[0] ^= in.w[0]; o.w[1] ^= in.w[1]; o.w[2] ^= in.w[2]; o.w[3] ^= in.w[3];
+    return o;
+}
+// inc_be (prg.rs:449-452): the counter's upper 64-bit lane
+__device__ __forceinline__ void ctr_add(B128 &c, uint32_t k) {
+    const uint64_t hi = (((uint64_t)c.w[3] << 32) | c.w[2]) + k;
+    c.w[2] = (uint32_t)hi; c.w[3] = (uint32_t)(hi >> 32);
+}
+__device__ __forceinline__ void fill_table(uint32_t *T, const HhTables *__restrict__ tab, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t k = tid; k < T_WORDS; k += nthreads) T[k] = tab->te0[k >> 5];
+}
+
+// little-endian loads from byte pointers of any alignment
+template <class P> __device__ __forceinline__ uint32_t ldb32(P p) {
+    return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
+}
+template <class P> __device__ __forceinline__ uint64_t ldb64(P p) { return (uint64_t)ldb32(p) | (uint64_t)ldb32(p + 4) << 32; }
+template <class P> __device__ __forceinline__ B128 ldb128(P p) {
+    B128 b;
+#pragma unroll
+    for (int k = 0; k < 4; k++) b.w[k] = ldb32(p + 4 * k);
+    return b;
+}
+
+// ---- SHA-256 (FIPS 180-4); `sha256 = "1.1.2"` digest() in the reference (vdpf.rs:211, protocol.rs:163-175) ----
+__device__ __forceinline__ void sha_init(uint32_t (&h)[8]) {
+    h[0] = 0x6a09e667; h[1] = 0xbb67ae85; h[2] = 0x3c6ef372; h[3] = 0xa54ff53a;
+    h[4] = 0x510e527f; h[5] = 0x9b05688c; h[6] = 0x1f83d9ab; h[7] = 0x5be0cd19;
+}
+__device__ __forceinline__ void sha_compress(uint32_t (&h)[8], uint32_t (&w)[16]) {
+    constexpr uint32_t K[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+        0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+        0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+        0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+        0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+        0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+        0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        if (i >= 16) {
+            const uint32_t x = w[(i + 1) & 15], y = w[(i + 14) & 15];
+            w[i & 15] += (rotl(x, 25) ^ rotl(x, 14) ^ (x >> 3)) + (rotl(y, 15) ^ rotl(y, 13) ^ (y >> 10)) + w[(i + 9) & 15];
+        }
+        const uint32_t t1 = hh + (rotl(e, 26) ^ rotl(e, 21) ^ rotl(e, 7)) + ((e & f) ^ (~e & g)) + K[i] + w[i & 15];
+        const uint32_t t2 = (rotl(a, 30) ^ rotl(a, 19) ^ rotl(a, 10)) + ((a & b) ^ (a & c) ^ (b & c));
+        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+// eight lower-case hex characters of v, most significant nibble first, as two big-endian message words
+__device__ __forceinline__ void hex_words(uint32_t v, uint32_t &w0, uint32_t &w1) {
+    uint32_t o[2] = {0, 0};
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t nib = (v >> (28 - 4 * k)) & 15;
+        o[k >> 2] = (o[k >> 2] << 8) | (nib < 10 ? 48 + nib : 87 + nib);
+    }
+    w0 = o[0]; w1 = o[1];
+}
+// SHA-256 of 64 bytes given as 16 little-endian words, written as the 64 hex characters in message-block form
+__device__ __forceinline__ void sha_of_pi_hex(const uint32_t (&pi)[16], uint32_t *__restrict__ out16) {
+    uint32_t h[8], w[16];
+    sha_init(h);
+#pragma unroll 1
+    for (int blk = 0; blk < 2; blk++) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) w[k] = blk == 0 ? __builtin_bswap32(pi[k]) : (k == 0 ? 0x80000000u : (k == 15 ? 512u : 0u));
+        sha_compress(h, w);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) hex_words(h[k], out16[2 * k], out16[2 * k + 1]);
+}
+
+// ------------------------------------------------------------------------------------------ main key
+__global__ __launch_bounds__(256) void k_hh_main(const uint8_t *__restrict__ keys, uint64_t stride, uint32_t depth,
+                                                 const HhTables *__restrict__ tab, uint32_t *__restrict__ dat,
+                                                 uint4 *__restrict__ tpc, uint32_t *__restrict__ buckg,
+                                                 uint8_t *__restrict__ ids, int32_t *__restrict__ status) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t N = 1u << depth, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint64_t i = blockIdx.x;
+    uint32_t *Tall = lds;
+    uint4 *seeds = reinterpret_cast<uint4 *>(lds + T_WORDS);
+    uint8_t *hdr = reinterpret_cast<uint8_t *>(seeds + N);
+    uint32_t *red = reinterpret_cast<uint32_t *>(hdr + HDR_BYTES);  // [4][256] + 2
+    uint8_t *cbits = reinterpret_cast<uint8_t *>(red + 1026);       // control bit of every node of the current level
+    __shared__ int s_ok;
+    const HhLayout L(depth);
+    const uint8_t *kb = keys + i * stride;
+
+    fill_table(Tall, tab, tid, 256);
+    for (uint32_t k = tid; k < L.sup; k += 256) hdr[k] = kb[k];
+    if (tid < 2) red[1024 + tid] = 0;
+    __syncthreads();
+    const uint32_t *T = Tall + (tid & 31);
+    const uint32_t *rk0 = tab->rk[0];
+
+    if (tid == 0) {
+        // what bincode, the indexing in eval_all and the asserts of eval_and_check would abort on
+        bool ok = hdr[L.key_id] <= 1 && ldb64(hdr + L.cw_len) == depth && ldb64(hdr + L.data_len) == 256 &&
+                  ldb64(hdr + L.sup_len) == HH_SUPPORT;
+        for (uint32_t l = 0; l < depth; l++) ok = ok && hdr[L.cw + 18 * l + 16] <= 1 && hdr[L.cw + 18 * l + 17] <= 1;
+        s_ok = ok;
+        status[i] = ok ? 0 : HH_ERR_KEY_FORMAT;
+        // testing id = AES_vk(id.to_le_bytes()), read little endian (server-hh/src/main.rs:258-259, prg.rs:650-655)
+        const B128 e = aes_enc(T, tab->rk[2], ldb128(hdr));
+        uint32_t *o = reinterpret_cast<uint32_t *>(ids + 16 * i);
+        o[0] = e.w[0]; o[1] = e.w[1]; o[2] = e.w[2]; o[3] = e.w[3];
+        const B128 root = ldb128(hdr + L.root);
+        seeds[0] = make_uint4(root.w[0], root.w[1], root.w[2], root.w[3]);
+        cbits[0] = hdr[L.key_id];
+    }
+    __syncthreads();
+    const uint64_t leaf0 = i * N;
+    if (!s_ok) {
+        uint32_t *d = dat + leaf0 * HH_BKT;
+        for (uint64_t k = tid; k < (uint64_t)N * HH_BKT; k += 256) d[k] = 0;
+        return;
+    }
+    const bool negate = hdr[L.key_id] != 0;
+
+    // ---- tree: level l has 2^l nodes at seeds[0 .. 2^l); children of node p go to 2p, 2p+1.  In place, from the
+    // last 256-parent chunk down, so that a chunk's children never land on parents still to be read.
+    for (uint32_t l = 0; l < depth; l++) {
+        const B128 cw = ldb128(hdr + L.cw + 18 * l);
+        const uint32_t cb0 = hdr[L.cw + 18 * l + 16], cb1 = hdr[L.cw + 18 * l + 17];
+        const uint32_t P = 1u << l;
+#pragma unroll 1
+        for (int c = (int)((P - 1) >> 8); c >= 0; c--) {
+            const uint32_t p = (uint32_t)c * 256 + tid;
+            uint4 s = make_uint4(0, 0, 0, 0);
+            uint32_t bit = 0;
+            if (p < P) { s = seeds[p]; bit = cbits[p]; }
+            __syncthreads();
+            if (p < P) {
+                // expand_direction(true, true): control bits from the seed's two low bits, which are then cleared
+                uint32_t bl = (s.x & 1) == 0, br = (s.x & 2) == 0;
+                B128 c0 = {{s.x & ~3u, s.y, s.z, s.w}};
+                B128 left = mmo(T, rk0, c0);
+                ctr_add(c0, 1);
+                B128 right = mmo(T, rk0, c0);
+                if (bit) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { left.w[k] ^= cw.w[k]; right.w[k] ^= cw.w[k]; }
+                    bl ^= cb0; br ^= cb1;
+                }
+                seeds[2 * p] = make_uint4(left.w[0], left.w[1], left.w[2], left.w[3]);
+                seeds[2 * p + 1] = make_uint4(right.w[0], right.w[1], right.w[2], right.w[3]);
+                cbits[2 * p] = (uint8_t)bl; cbits[2 * p + 1] = (uint8_t)br;
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- leaf hashes: tilde_pi = mmo_hash2to4(seed, x) with x = IntModN::zero() at EVERY leaf (IntModN::one() has
+    // val 0, common/src/group.rs:448-453, so `x.add(&GIn::one())` never moves), corrected by cs when lsb(seed) = 1
+    {
+        B128 cs[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) cs[k] = ldb128(hdr + L.cs + 16 * k);
+#pragma unroll 1
+        for (uint32_t x = tid; x < N; x += 256) {
+            const uint4 s = seeds[x];
+            const B128 sd = {{s.x, s.y, s.z, s.w}};
+            const B128 s1 = mmo(T, rk0, sd);
+            const B128 s3 = mmo(T, rk0, s1);
+            const uint32_t m = 0u - (s.x & 1);
+            uint4 *o = tpc + (leaf0 + x) * 4;
+            o[0] = make_uint4(tab->cx[0][0] ^ (cs[0].w[0] & m), tab->cx[0][1] ^ (cs[0].w[1] & m), tab->cx[0][2] ^ (cs[0].w[2] & m), tab->cx[0][3] ^ (cs[0].w[3] & m));
+            o[1] = make_uint4(s1.w[0] ^ (cs[1].w[0] & m), s1.w[1] ^ (cs[1].w[1] & m), s1.w[2] ^ (cs[1].w[2] & m), s1.w[3] ^ (cs[1].w[3] & m));
+            o[2] = make_uint4(tab->cx[0][4] ^ (cs[2].w[0] & m), tab->cx[0][5] ^ (cs[2].w[1] & m), tab->cx[0][6] ^ (cs[2].w[2] & m), tab->cx[0][7] ^ (cs[2].w[3] & m));
+            o[3] = make_uint4(s3.w[0] ^ (cs[3].w[0] & m), s3.w[1] ^ (cs[3].w[1] & m), s3.w[2] ^ (cs[3].w[2] & m), s3.w[3] ^ (cs[3].w[3] & m));
+        }
+    }
+
+    // ---- convert::<Bucket<u32>>: 1032 bytes = counters seed+0 .. seed+64 (the last half used); one wavefront per
+    // leaf, lane j takes counter j, so a leaf is one 1 KiB coalesced store; the sum over leaves stays in registers
+    {
+        const B128 oc = ldb128(hdr + L.oc + 16 * lane);
+        uint32_t acc[4] = {0, 0, 0, 0};
+#pragma unroll 1
+        for (uint32_t x = wv; x < N; x += 4) {
+            const uint4 s = seeds[x];
+            B128 c = {{s.x, s.y, s.z, s.w}};
+            ctr_add(c, lane);
+            B128 o = mmo(T, rk0, c);
+            const uint32_t m = 0u - (s.x & 1);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                o.w[k] += oc.w[k] & m;
+                if (negate) o.w[k] = 0u - o.w[k];
+                acc[k] += o.w[k];
+            }
+            uint2 *d = reinterpret_cast<uint2 *>(dat + (leaf0 + x) * HH_BKT + 4 * lane);  // 8-byte aligned only
+            d[0] = make_uint2(o.w[0], o.w[1]);
+            d[1] = make_uint2(o.w[2], o.w[3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) red[wv * 256 + 4 * lane + k] = acc[k];
+        // sign_data and ctr: the first 8 bytes of counter seed+64
+        const uint32_t oc0 = ldb32(hdr + L.oc + 1024), oc1 = ldb32(hdr + L.oc + 1028);
+        uint32_t t0 = 0, t1 = 0;
+#pragma unroll 1
+        for (uint32_t x = tid; x < N; x += 256) {
+            const uint4 s = seeds[x];
+            B128 c = {{s.x, s.y, s.z, s.w}};
+            ctr_add(c, 64);
+            const B128 o = mmo(T, rk0, c);
+            const uint32_t m = 0u - (s.x & 1);
+            uint32_t a = o.w[0] + (oc0 & m), b = o.w[1] + (oc1 & m);
+            if (negate) { a = 0u - a; b = 0u - b; }
+            *reinterpret_cast<uint2 *>(dat + (leaf0 + x) * HH_BKT + 256) = make_uint2(a, b);
+            t0 += a; t1 += b;
+        }
+        atomicAdd(&red[1024], t0);
+        atomicAdd(&red[1025], t1);
+    }
+    __syncthreads();
+    buckg[i * HH_BKT + tid] = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid];
+    if (tid < 2) buckg[i * HH_BKT + 256 + tid] = red[1024 + tid];
+}
+
+// ------------------------------------------------------------------------------------------ support keys
+// VDPFKey<u32>::eval_all::<bool>: one level, two leaves, hashed index x = false, true
+__global__ __launch_bounds__(256) void k_hh_support(const uint8_t *__restrict__ keys, uint64_t stride, uint32_t n, uint32_t depth,
+                                                    const HhTables *__restrict__ tab, uint32_t *__restrict__ proofblk,
+                                                    uint32_t *__restrict__ supd, int32_t *__restrict__ status) {
+    __shared__ uint32_t Tall[T_WORDS];
+    const uint32_t tid = threadIdx.x;
+    fill_table(Tall, tab, tid, 256);
+    __syncthreads();
+    const uint32_t *T = Tall + (tid & 31);
+    const uint64_t g = (uint64_t)blockIdx.x * 256 + tid;
+    if (g >= (uint64_t)n * HH_SUPPORT) return;
+    const uint64_t i = g / HH_SUPPORT;
+    const uint32_t sup = (uint32_t)(g - i * HH_SUPPORT);
+    const HhLayout L(depth);
+    const uint8_t *p = keys + i * stride + L.sup + (uint64_t)HH_SUPPORT_LEN * sup;
+    const uint32_t kid = p[0];
+    const B128 root = ldb128(p + 1);
+    const B128 cw = ldb128(p + 25);
+    const bool ok = kid <= 1 && ldb64(p + 17) == 1 && p[41] <= 1 && p[42] <= 1;
+    if (!ok) { status[i] = HH_ERR_KEY_FORMAT; return; }
+    uint32_t cs[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) cs[k] = ldb32(p + 43 + 4 * k);
+    const uint32_t oc = ldb32(p + 107);
+    const uint32_t *rk0 = tab->rk[0], *rk1 = tab->rk[1];
+
+    B128 c0 = {{root.w[0] & ~3u, root.w[1], root.w[2], root.w[3]}};
+    B128 leaf[2];
+    leaf[0] = mmo(T, rk0, c0);
+    ctr_add(c0, 1);
+    leaf[1] = mmo(T, rk0, c0);
+    uint32_t pi[16], d[2];
+#pragma unroll
+    for (int k = 0; k < 16; k++) pi[k] = cs[k];
+#pragma unroll 1
+    for (int x = 0; x < 2; x++) {
+        B128 s = leaf[0];
+        if (x) s = leaf[1];
+        if (kid) { s.w[0] ^= cw.w[0]; s.w[1] ^= cw.w[1]; s.w[2] ^= cw.w[2]; s.w[3] ^= cw.w[3]; }  // state.bit = key_id at the root
+        const B128 s1 = mmo(T, rk0, s);
+        const B128 s3 = mmo(T, rk0, s1);
+        const uint32_t m = 0u - (s.w[0] & 1);
+        // convert::<u32>: next_u32 -> refill -> the first four bytes of MMO_0(seed), which is s1
+        uint32_t word = s1.w[0] + (oc & m);
+        if (kid) word = 0u - word;
+        d[x] = word;
+        B128 hin[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            hin[0].w[k] = pi[k] ^ tab->cx[x][k] ^ (cs[k] & m);
+            hin[1].w[k] = pi[4 + k] ^ s1.w[k] ^ (cs[4 + k] & m);
+            hin[2].w[k] = pi[8 + k] ^ tab->cx[x][4 + k] ^ (cs[8 + k] & m);
+            hin[3].w[k] = pi[12 + k] ^ s3.w[k] ^ (cs[12 + k] & m);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const B128 ho = mmo(T, rk1, hin[b]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) pi[4 * b + k] ^= ho.w[k];
+        }
+    }
+    supd[g * 2] = d[0];
+    supd[g * 2 + 1] = d[1];
+    sha_of_pi_hex(pi, proofblk + (i * (HH_SUPPORT + 1) + 1 + sup) * 16);
+}
+
+// ------------------------------------------------------------------------------------------ proof chain of the main key
+__global__ __launch_bounds__(64) void k_hh_chain(const uint8_t *__restrict__ keys, uint64_t stride, uint32_t n, uint32_t depth,
+                                                 const HhTables *__restrict__ tab, const uint4 *__restrict__ tpc,
+                                                 uint32_t *__restrict__ proofblk, const int32_t *__restrict__ status) {
+    __shared__ uint32_t Tall[T_WORDS];
+    const uint32_t tid = threadIdx.x;
+    fill_table(Tall, tab, tid, 64);
+    __syncthreads();
+    const uint32_t *T = Tall + (tid & 31);
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + tid;
+    if (i >= n || status[i] != 0) return;
+    const HhLayout L(depth);
+    const uint8_t *p = keys + i * stride + L.cs;
+    const uint32_t *rk1 = tab->rk[1];
+    uint32_t pi[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) pi[k] = ldb32(p + 4 * k);
+    const uint32_t N = 1u << depth;
+    const uint4 *tp = tpc + i * N * 4;
+    uint4 nx[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) nx[b] = tp[b];
+#pragma unroll 1
+    for (uint32_t x = 0; x < N; x++) {
+        B128 hin[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            hin[b].w[0] = pi[4 * b] ^ nx[b].x; hin[b].w[1] = pi[4 * b + 1] ^ nx[b].y;
+            hin[b].w[2] = pi[4 * b + 2] ^ nx[b].z; hin[b].w[3] = pi[4 * b + 3] ^ nx[b].w;
+        }
+        if (x + 1 < N) {
+#pragma unroll
+            for (int b = 0; b < 4; b++) nx[b] = tp[(x + 1) * 4 + b];
+        }
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const B128 ho = mmo(T, rk1, hin[b]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) pi[4 * b + k] ^= ho.w[k];
+        }
+    }
+    sha_of_pi_hex(pi, proofblk + i * (HH_SUPPORT + 1) * 16);
+}
+
+// ------------------------------------------------------------------------------------------ folding and the tag
+// Three SHA-256 messages per key chain, streamed through one compression site:
+//   A  bytes of the folded bucket (258 u32, little endian)                 17 blocks
+//   B  bytes of the support sums (257 u32)                                 17 blocks
+//   C  the proof string: hex(main) | 257 x hex(support) | hex(A) | hex(B)  260 blocks + padding
+__global__ __launch_bounds__(64) void k_hh_final(const uint8_t *__restrict__ keys, uint64_t stride, uint32_t n, uint32_t depth,
+                                                 const uint32_t *__restrict__ proofblk, const uint32_t *__restrict__ supd,
+                                                 const uint32_t *__restrict__ buckg, uint8_t *__restrict__ tags,
+                                                 const int32_t *__restrict__ status) {
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t *tag = reinterpret_cast<uint32_t *>(tags + 64 * i);
+    if (status[i] != 0) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) tag[k] = 0;
+        return;
+    }
+    const HhLayout L(depth);
+    const bool kid = keys[i * stride + L.key_id] != 0;
+    const uint32_t *bk = buckg + i * HH_BKT, *sd = supd + i * HH_SUPPORT * 2, *pb = proofblk + i * (HH_SUPPORT + 1) * 16;
+    uint32_t h[8], hexA[16], hexB[16], w[16];
+    sha_init(h);
+#pragma unroll 1
+    for (uint32_t blk = 0; blk < 17 + 17 + 261; blk++) {
+        if (blk < 34) {
+            const bool isA = blk < 17;
+            const uint32_t b = isA ? blk : blk - 17, words = isA ? HH_BKT : HH_SUPPORT;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t e = 16 * b + k;
+                uint32_t v = 0;
+                if (e < words) {
+                    const uint32_t d0 = e < HH_SUPPORT ? sd[2 * e] : 0, d1 = e < HH_SUPPORT ? sd[2 * e + 1] : 0;
+                    if (isA) {
+                        // buck -= (right - left) per support key; key 1 also takes 1 off ctr and negates (protocol.rs:99-126)
+                        v = bk[e] - (d1 - d0);
+                        if (kid) { if (e == HH_BKT - 1) v -= 1; v = 0u - v; }
+                    } else {
+                        v = d0 + d1;                      // must be 1 across the two servers (protocol.rs:104-108, 143-148)
+                        if (kid) v = 0u - (v - 1);
+                    }
+                    v = __builtin_bswap32(v);             // little-endian bytes of the u32 as a big-endian message word
+                } else if (e == words) v = 0x80000000u;
+                else if (e == 271) v = words * 32;        // message length in bits
+                w[k] = v;
+            }
+        } else {
+            const uint32_t b = blk - 34;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                uint32_t v;
+                if (b < HH_SUPPORT + 1) v = pb[16 * b + k];
+                else if (b == HH_SUPPORT + 1) v = hexA[k];
+                else if (b == HH_SUPPORT + 2) v = hexB[k];
+                else v = k == 0 ? 0x80000000u : (k == 15 ? 64u * (HH_SUPPORT + 3) * 8 : 0u);
+                w[k] = v;
+            }
+        }
+        sha_compress(h, w);
+        if (blk == 16 || blk == 33) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                uint32_t a, b2;
+                hex_words(h[k], a, b2);
+                if (blk == 16) { hexA[2 * k] = a; hexA[2 * k + 1] = b2; } else { hexB[2 * k] = a; hexB[2 * k + 1] = b2; }
+            }
+            sha_init(h);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        uint32_t a, b;
+        hex_words(h[k], a, b);
+        tag[2 * k] = __builtin_bswap32(a);
+        tag[2 * k + 1] = __builtin_bswap32(b);
+    }
+}
+
+}  // namespace
+
+size_t hh_main_lds_bytes(uint32_t depth) {
+    return 4 * (size_t)T_WORDS + 16 * ((size_t)1 << depth) + HDR_BYTES + 4 * 1026 + ((size_t)1 << depth) + 16;
+}
+
+int launch_hh_eval(const uint8_t *d_keys, uint64_t stride, uint32_t n, uint32_t depth, const HhTables *d_tab,
+                   const HhWork &w, uint32_t *d_dat, uint8_t *d_tags, uint8_t *d_ids, int32_t *d_status,
+                   hipStream_t stream) {
+    if (!n) return 0;
+    const size_t lds = hh_main_lds_bytes(depth);
+    static size_t lds_allowed = 64 * 1024;
+    if (lds > lds_allowed) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_hh_main), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        lds_allowed = lds;
+    }
+    hipLaunchKernelGGL(k_hh_main, dim3(n), dim3(256), lds, stream, d_keys, stride, depth, d_tab, d_dat, w.tpc, w.buckg, d_ids, d_status);
+    const uint64_t sup_threads = (uint64_t)n * HH_SUPPORT;
+    hipLaunchKernelGGL(k_hh_support, dim3((uint32_t)((sup_threads + 255) / 256)), dim3(256), 0, stream, d_keys, stride, n, depth, d_tab,
+                       w.proofblk, w.supd, d_status);
+    hipLaunchKernelGGL(k_hh_chain, dim3((n + 63) / 64), dim3(64), 0, stream, d_keys, stride, n, depth, d_tab, w.tpc, w.proofblk, d_status);
+    hipLaunchKernelGGL(k_hh_final, dim3((n + 63) / 64), dim3(64), 0, stream, d_keys, stride, n, depth, w.proofblk, w.supd, w.buckg, d_tags,
+                       d_status);
+    return (int)hipGetLastError();
+}
+
+}  // namespace wh

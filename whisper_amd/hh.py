@@ -1,0 +1,114 @@
+"""Host-side mirror of the reference's heavy-hitter server surface.
+
+Names follow the Rust crates: `BCSketch::gen_key_chain` / `eval_and_check` (hhcore/src/protocol.rs:17-28),
+`aggregate_hhs` (server-hh/src/main.rs:53-110), `Bucket` = 256 data + sign_data + ctr counters of `AggRing = u32`
+(hhcore/src/bucket.rs:5-12, hhcore/src/lib.rs:13).  Key chains cross this API as the bincode bytes the servers
+receive (serialize/src/lib.rs:72-80); `eval_and_check` runs over a whole batch, as the GPU wants it.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import lib, WhError
+
+BUCKET_WORDS = 258  # STRING_SIZE + 2
+MAX_DEPTH = 11      # num_buckets <= 2048 (server-hh/src/main.rs:428-436)
+
+
+def key_chain_len(depth):
+    n = int(lib.wh_hh_key_chain_len(depth))
+    if not n:
+        raise WhError(-1, f"depth {depth} outside 1..{MAX_DEPTH}")
+    return n
+
+
+def gen_key_chain(depth, client_id, alpha, bucket, rng_seed):
+    """CPU client: `bucket.gen_key_chain(id, IntModN::<2^depth>::from_u16(alpha))` -> (alice bytes, bob bytes)."""
+    bk = np.ascontiguousarray(bucket, dtype=np.uint32)
+    if bk.shape != (BUCKET_WORDS,):
+        raise ValueError("bucket must hold 258 u32")
+    n = 16 + 1 + 16 + 8 + 18 * depth + 64 + 8 + 4 * BUCKET_WORDS + 8 + 257 * 111
+    k0 = np.zeros(n, np.uint8); k1 = np.zeros(n, np.uint8)
+    cid = np.frombuffer(int(client_id).to_bytes(16, "little"), np.uint8).copy()
+    seed = np.frombuffer(bytes(rng_seed), np.uint8).copy()
+    if seed.size != 32:
+        raise ValueError("rng_seed must be 32 bytes")
+    rc = lib.wh_hh_gen_key_chain(depth, cid.ctypes.data, alpha, bk.ctypes.data, seed.ctypes.data, k0.ctypes.data, k1.ctypes.data)
+    if rc:
+        raise WhError(rc, "gen_key_chain")
+    return k0, k1
+
+
+class HeavyHitters:
+    """One server's heavy-hitter expansion + aggregation bound to one GPU."""
+
+    def __init__(self, num_buckets, device=0):
+        depth = int(num_buckets).bit_length() - 1
+        if num_buckets != 1 << depth or not 1 <= depth <= MAX_DEPTH:
+            raise ValueError("num_buckets must be a power of two in 2..2048")
+        self.num_buckets, self.depth = num_buckets, depth
+        self.key_len = key_chain_len(depth)
+        self._ctx = C.c_void_p()
+        rc = lib.wh_hh_ctx_create(device, C.byref(self._ctx))
+        if rc:
+            raise WhError(rc, "wh_hh_ctx_create (is a GPU present? there is no CPU fallback)")
+        self.n_last = 0
+
+    def close(self):
+        if self._ctx:
+            lib.wh_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc:
+            raise WhError(rc, f"{what}: {lib.wh_last_error(self._ctx).decode()}")
+
+    @property
+    def stream(self):
+        return lib.wh_ctx_stream(self._ctx)
+
+    def synchronize(self):
+        self._chk(lib.wh_ctx_synchronize(self._ctx), "synchronize")
+
+    def eval_and_check(self, verify_key, key_chains):
+        """key_chains: uint8 [n, stride >= key_len].  Returns (tags [n] of 64-char str, testing_ids [n] int, status int32[n]);
+        the bucket vectors stay in HBM for aggregate_hhs / buckets."""
+        keys = np.ascontiguousarray(key_chains, dtype=np.uint8)
+        n, stride = keys.shape
+        vk = np.frombuffer(bytes(verify_key), np.uint8).copy()
+        tags = np.zeros((n, 64), np.uint8); ids = np.zeros((n, 16), np.uint8); status = np.zeros(n, np.int32)
+        self._chk(lib.wh_hh_eval_and_check_batch(self._ctx, vk.ctypes.data, keys.ctypes.data, stride, n, self.depth,
+                                                 tags.ctypes.data, ids.ctypes.data, status.ctypes.data), "hh_eval_and_check")
+        self.n_last = n
+        return ([bytes(t).decode("ascii") if s == 0 else "" for t, s in zip(tags, status)],
+                [int.from_bytes(bytes(i), "little") for i in ids], status)
+
+    def eval_and_check_dev(self, verify_key, d_keys, stride, n, d_dat, d_tags, d_ids, d_status):
+        """Device pointers (ints); d_dat may be None to keep the bucket vectors in the context.  Asynchronous."""
+        vk = np.frombuffer(bytes(verify_key), np.uint8).copy()
+        self._chk(lib.wh_hh_eval_and_check_batch_dev(self._ctx, vk.ctypes.data, d_keys, stride, n, self.depth, d_dat, d_tags,
+                                                     d_ids, d_status), "hh_eval_and_check_dev")
+        self.n_last = n
+
+    def buckets(self):
+        """Vec<Bucket<u32>> of every key chain of the last batch: uint32 [n, num_buckets, 258]."""
+        out = np.zeros((self.n_last, self.num_buckets, BUCKET_WORDS), np.uint32)
+        if self.n_last:
+            self._chk(lib.wh_hh_buckets(self._ctx, out.ctypes.data), "hh_buckets")
+        return out
+
+    def aggregate_hhs(self, keep=None):
+        """Sum of the kept clients' bucket vectors: uint32 [num_buckets, 258]."""
+        acc = np.zeros((self.num_buckets, BUCKET_WORDS), np.uint32)
+        k = None if keep is None else np.ascontiguousarray(keep, dtype=np.uint8)
+        self._chk(lib.wh_hh_aggregate(self._ctx, None if k is None else k.ctypes.data, acc.ctypes.data), "hh_aggregate")
+        return acc
+
+    def aggregate_hhs_dev(self, d_keep, d_acc, accumulate=False):
+        self._chk(lib.wh_hh_aggregate_dev(self._ctx, d_keep, d_acc, 1 if accumulate else 0), "hh_aggregate_dev")

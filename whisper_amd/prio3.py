@@ -234,7 +234,7 @@ class Prio3:
         self._chk(fn(self._ctx, d_buckets, d_keep, n, words, d_acc), "hh_bucket_sum")
 
     # ---- measurement ----
-    KERNELS = ("parse", "expand", "hash", "query", "aggregate", "hh_sum", "meas")
+    KERNELS = ("parse", "expand", "hash", "query", "aggregate", "hh_sum", "meas", "hh_eval")
 
     def set_profiling(self, on=True):
         self._chk(lib.wh_ctx_set_profiling(self._ctx, int(on)), "set_profiling")
