@@ -142,7 +142,6 @@ __global__ __launch_bounds__(256) void k_hh_main(const uint8_t *__restrict__ key
     uint8_t *hdr = reinterpret_cast<uint8_t *>(seeds + N);
     uint32_t *red = reinterpret_cast<uint32_t *>(hdr + HDR_BYTES);  // [4][256] + 2
     uint8_t *cbits = reinterpret_cast<uint8_t *>(red + 1026);       // control bit of every node of the current level
-    __shared__ int s_ok;
     const HhLayout L(depth);
     const uint8_t *kb = keys + i * stride;
 
@@ -153,13 +152,18 @@ __global__ __launch_bounds__(256) void k_hh_main(const uint8_t *__restrict__ key
     const uint32_t *T = Tall + (tid & 31);
     const uint32_t *rk0 = tab->rk[0];
 
+    // what bincode, the indexing in eval_all and the asserts of eval_and_check would abort on: the main key's header
+    // (thread 0) and every support key's (one per thread)
+    int ok_local = 1;
+    for (uint32_t sk = tid; sk < HH_SUPPORT; sk += 256) {
+        const uint8_t *p = kb + L.sup + HH_SUPPORT_LEN * sk;
+        ok_local &= p[0] <= 1 && ldb64(p + 17) == 1 && p[41] <= 1 && p[42] <= 1;
+    }
     if (tid == 0) {
-        // what bincode, the indexing in eval_all and the asserts of eval_and_check would abort on
         bool ok = hdr[L.key_id] <= 1 && ldb64(hdr + L.cw_len) == depth && ldb64(hdr + L.data_len) == 256 &&
                   ldb64(hdr + L.sup_len) == HH_SUPPORT;
         for (uint32_t l = 0; l < depth; l++) ok = ok && hdr[L.cw + 18 * l + 16] <= 1 && hdr[L.cw + 18 * l + 17] <= 1;
-        s_ok = ok;
-        status[i] = ok ? 0 : HH_ERR_KEY_FORMAT;
+        ok_local &= ok;
         // testing id = AES_vk(id.to_le_bytes()), read little endian (server-hh/src/main.rs:258-259, prg.rs:650-655)
         const B128 e = aes_enc(T, tab->rk[2], ldb128(hdr));
         uint32_t *o = reinterpret_cast<uint32_t *>(ids + 16 * i);
@@ -168,9 +172,10 @@ __global__ __launch_bounds__(256) void k_hh_main(const uint8_t *__restrict__ key
         seeds[0] = make_uint4(root.w[0], root.w[1], root.w[2], root.w[3]);
         cbits[0] = hdr[L.key_id];
     }
-    __syncthreads();
+    const int all_ok = __syncthreads_and(ok_local);
+    if (tid == 0) status[i] = all_ok ? 0 : HH_ERR_KEY_FORMAT;
     const uint64_t leaf0 = i * N;
-    if (!s_ok) {
+    if (!all_ok) {
         uint32_t *d = dat + leaf0 * HH_BKT;
         for (uint64_t k = tid; k < (uint64_t)N * HH_BKT; k += 256) d[k] = 0;
         return;
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(256) void k_hh_main(const uint8_t *__restrict__ key
 // VDPFKey<u32>::eval_all::<bool>: one level, two leaves, hashed index x = false, true
 __global__ __launch_bounds__(256) void k_hh_support(const uint8_t *__restrict__ keys, uint64_t stride, uint32_t n, uint32_t depth,
                                                     const HhTables *__restrict__ tab, uint32_t *__restrict__ proofblk,
-                                                    uint32_t *__restrict__ supd, int32_t *__restrict__ status) {
+                                                    uint32_t *__restrict__ supd, const int32_t *__restrict__ status) {
     __shared__ uint32_t Tall[T_WORDS];
     const uint32_t tid = threadIdx.x;
     fill_table(Tall, tab, tid, 256);
@@ -297,8 +302,7 @@ __global__ __launch_bounds__(256) void k_hh_support(const uint8_t *__restrict__ 
     const uint32_t kid = p[0];
     const B128 root = ldb128(p + 1);
     const B128 cw = ldb128(p + 25);
-    const bool ok = kid <= 1 && ldb64(p + 17) == 1 && p[41] <= 1 && p[42] <= 1;
-    if (!ok) { status[i] = HH_ERR_KEY_FORMAT; return; }
+    if (status[i] != 0) return;  // rejected by k_hh_main (it checks every support key's header too)
     uint32_t cs[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) cs[k] = ldb32(p + 43 + 4 * k);
