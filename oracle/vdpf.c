@@ -106,6 +106,24 @@ __attribute__((target("aes,sse2"))) static void aes_ni(const aes_rk *k, const ui
     _mm_storeu_si128((__m128i *)out, s);
 }
 #endif
+#if defined(__x86_64__)
+/* eight counters at once, as refill8 hands them to encrypt_blocks (prg.rs:368-403): the AES-NI pipeline stays full */
+__attribute__((target("aes,sse2"))) static void mmo8_ni(const aes_rk *k, const uint8_t ctr[16], uint8_t out[128]) {
+    const __m128i *rk = (const __m128i *)k->rk;
+    const __m128i one_hi = _mm_set_epi64x(1, 0);
+    __m128i c[8], s[8];
+    c[0] = _mm_loadu_si128((const __m128i *)ctr);
+    for (int i = 1; i < 8; i++) c[i] = _mm_add_epi64(c[i - 1], one_hi);
+    const __m128i k0 = _mm_loadu_si128(rk);
+    for (int i = 0; i < 8; i++) s[i] = _mm_xor_si128(c[i], k0);
+    for (int r = 1; r < 10; r++) {
+        const __m128i kr = _mm_loadu_si128(rk + r);
+        for (int i = 0; i < 8; i++) s[i] = _mm_aesenc_si128(s[i], kr);
+    }
+    const __m128i kl = _mm_loadu_si128(rk + 10);
+    for (int i = 0; i < 8; i++) _mm_storeu_si128((__m128i *)(out + 16 * i), _mm_xor_si128(_mm_aesenclast_si128(s[i], kl), c[i]));
+}
+#endif
 static void aes_enc(const aes_rk *k, const uint8_t in[16], uint8_t out[16]) {
 #if defined(__x86_64__)
     if (have_aesni) { aes_ni(k, in, out); return; }
@@ -206,6 +224,11 @@ static uint32_t convert_u32(const uint8_t seed[16]) {
 static void convert_bucket(const uint8_t seed[16], uint32_t out[BKT]) {
     uint8_t c[16], buf[72 * 16];
     memcpy(c, seed, 16);
+#if defined(__x86_64__)
+    if (have_aesni) {
+        for (int i = 0; i < 9; i++) { mmo8_ni(&K0, c, buf + 128 * i); ctr_add(c, 8); }
+    } else
+#endif
     for (int i = 0; i < 72; i++) { mmo(&K0, c, buf + 16 * i); ctr_add(c, 1); }
     for (int i = 0; i < BKT; i++) out[i] = (uint32_t)buf[4 * i] | (uint32_t)buf[4 * i + 1] << 8 | (uint32_t)buf[4 * i + 2] << 16 | (uint32_t)buf[4 * i + 3] << 24;
 }

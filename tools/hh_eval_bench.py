@@ -68,7 +68,7 @@ out = {"buckets": N, "clients": n, "key_chain_bytes": ln, "eval_ms": ev, "aggreg
 if not a.no_cpu:
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as o
-    m = min(n, max(a.cpu_threads * 4, 64))
+    m = min(n, a.cpu_threads * 1500)   # about ten seconds of host work at 512 buckets
     t0 = time.time()
     odat, otags, oids, ost = o.hh_eval_and_check_batch(depth, vk, keys[:m], nthreads=a.cpu_threads)
     cpu_s = time.time() - t0

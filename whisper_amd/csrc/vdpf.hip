@@ -28,32 +28,59 @@ struct B128 { uint32_t w[4]; };
 
 __device__ __forceinline__ uint32_t rotl(uint32_t v, int n) { return __builtin_rotateleft32(v, n); }
 
-// T points at this lane's copy of entry 0; rk = 44 round-key words (uniform)
-__device__ __forceinline__ B128 aes_enc(const uint32_t *T, const uint32_t *__restrict__ rk, const B128 &in) {
+// AES-128 with NT tables in LDS.  NT = 1: Te0, three rotates per column.  NT = 2: Te0 and Te0 <<< 16, one rotate per
+// column.  NT = 4: Te0 <<< 8t, none.  Table t starts t * 32 KiB after table 0.  Addresses are formed as integers --
+// (byte << 7) + lane address, one v_bfe + one v_lshl_add per read, the table offset in the instruction's immediate --
+// and the column is two three-input XORs (v_bitop3).  rk = 44 round-key words (uniform).
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+struct TabRef { uint32_t a, b; };  // byte address of this lane's copy of entry 0: a = table 0, b = table 2 (NT = 4)
+__device__ __forceinline__ TabRef tab_ref(const uint32_t *tables, uint32_t tid) {
+    const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t *)tables + 4 * (tid & 31);
+    return TabRef{base, base + 8 * T_WORDS};
+}
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+template <int NT> __device__ __forceinline__ uint32_t te(const TabRef &R, int t, uint32_t x, int sh) {
+    static_assert(NT == 1 || NT == 2 || NT == 4, "table count");
+    uint32_t byte;
+    if (sh == 24) byte = x >> 24;
+    else if (sh == 0) asm("v_bfe_u32 %0, %1, 0, 8" : "=v"(byte) : "v"(x));  // kept as one instruction: (x & 0xff) << 7 would
+    else byte = __builtin_amdgcn_ubfe(x, sh, 8);                            // be rewritten into shift, mask and add
+    const uint32_t idx = byte << 7;
+    if (NT == 4) return *(lds_cu32 *)(uintptr_t)((t < 2 ? R.a : R.b) + idx + (t & 1) * 4 * T_WORDS);
+    if (NT == 2) return *(lds_cu32 *)(uintptr_t)(R.a + idx + (t >> 1) * 4 * T_WORDS);   // t = 0 or 2
+    return *(lds_cu32 *)(uintptr_t)(R.a + idx);
+}
+template <int NT> __device__ __forceinline__ uint32_t aes_col(const TabRef &R, uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t k) {
+    if (NT == 4) return xor3(xor3(te<4>(R, 0, a, 0), te<4>(R, 1, b, 8), te<4>(R, 2, c, 16)), te<4>(R, 3, d, 24), k);
+    if (NT == 2) return xor3(te<2>(R, 0, a, 0), te<2>(R, 2, c, 16), k) ^ rotl(te<2>(R, 0, b, 8) ^ te<2>(R, 2, d, 24), 8);
+    return xor3(xor3(te<1>(R, 0, a, 0), rotl(te<1>(R, 0, b, 8), 8), rotl(te<1>(R, 0, c, 16), 16)), rotl(te<1>(R, 0, d, 24), 24), k);
+}
+// last round: SubBytes + ShiftRows only.  S[x] sits in bytes 1, 2 of table 0; 2, 3 of table 1; 0, 3 of table 2; 0, 1 of table 3
+template <int NT> __device__ __forceinline__ uint32_t aes_last(const TabRef &R, uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t k) {
+    if (NT == 4) return ((te<4>(R, 2, a, 0) & 0xff) | (te<4>(R, 3, b, 8) & 0xff00) | (te<4>(R, 0, c, 16) & 0xff0000) | (te<4>(R, 1, d, 24) & 0xff000000)) ^ k;
+    if (NT == 2) return ((te<2>(R, 2, a, 0) & 0xff) | (te<2>(R, 0, b, 8) & 0xff00) | (te<2>(R, 0, c, 16) & 0xff0000) | (te<2>(R, 2, d, 24) & 0xff000000)) ^ k;
+    return (((te<1>(R, 0, a, 0) >> 8) & 0xff) | (te<1>(R, 0, b, 8) & 0xff00) | (te<1>(R, 0, c, 16) & 0xff0000) | ((te<1>(R, 0, d, 24) << 8) & 0xff000000)) ^ k;
+}
+template <int NT = 1> __device__ __forceinline__ B128 aes_enc(const TabRef &R, const uint32_t *__restrict__ rk, const B128 &in) {
     uint32_t s0 = in.w[0] ^ rk[0], s1 = in.w[1] ^ rk[1], s2 = in.w[2] ^ rk[2], s3 = in.w[3] ^ rk[3];
-#define TE(x, sh) T[(((x) >> (sh)) & 0xff) << 5]
 #pragma unroll
     for (int r = 1; r < 10; r++) {
-        const uint32_t t0 = TE(s0, 0) ^ rotl(TE(s1, 8), 8) ^ rotl(TE(s2, 16), 16) ^ rotl(TE(s3, 24), 24) ^ rk[4 * r];
-        const uint32_t t1 = TE(s1, 0) ^ rotl(TE(s2, 8), 8) ^ rotl(TE(s3, 16), 16) ^ rotl(TE(s0, 24), 24) ^ rk[4 * r + 1];
-        const uint32_t t2 = TE(s2, 0) ^ rotl(TE(s3, 8), 8) ^ rotl(TE(s0, 16), 16) ^ rotl(TE(s1, 24), 24) ^ rk[4 * r + 2];
-        const uint32_t t3 = TE(s3, 0) ^ rotl(TE(s0, 8), 8) ^ rotl(TE(s1, 16), 16) ^ rotl(TE(s2, 24), 24) ^ rk[4 * r + 3];
+        const uint32_t t0 = aes_col<NT>(R, s0, s1, s2, s3, rk[4 * r]);
+        const uint32_t t1 = aes_col<NT>(R, s1, s2, s3, s0, rk[4 * r + 1]);
+        const uint32_t t2 = aes_col<NT>(R, s2, s3, s0, s1, rk[4 * r + 2]);
+        const uint32_t t3 = aes_col<NT>(R, s3, s0, s1, s2, rk[4 * r + 3]);
         s0 = t0; s1 = t1; s2 = t2; s3 = t3;
     }
-    // last round: SubBytes + ShiftRows only; S[x] is byte 1 (and 2) of Te0[x]
-#define LAST(a, b, c, d) (((TE(a, 0) >> 8) & 0xff) | (TE(b, 8) & 0xff00) | (TE(c, 16) & 0xff0000) | ((TE(d, 24) << 8) & 0xff000000))
     B128 o;
-    o.w[0] = LAST(s0, s1, s2, s3) ^ rk[40];
-    o.w[1] = LAST(s1, s2, s3, s0) ^ rk[41];
-    o.w[2] = LAST(s2, s3, s0, s1) ^ rk[42];
-    o.w[3] = LAST(s3, s0, s1, s2) ^ rk[43];
-#undef LAST
-#undef TE
+    o.w[0] = aes_last<NT>(R, s0, s1, s2, s3, rk[40]);
+    o.w[1] = aes_last<NT>(R, s1, s2, s3, s0, rk[41]);
+    o.w[2] = aes_last<NT>(R, s2, s3, s0, s1, rk[42]);
+    o.w[3] = aes_last<NT>(R, s3, s0, s1, s2, rk[43]);
     return o;
 }
 // Matyas-Meyer-Oseas (prg.rs:311-331)
-__device__ __forceinline__ B128 mmo(const uint32_t *T, const uint32_t *__restrict__ rk, const B128 &in) {
-    B128 o = aes_enc(T, rk, in);
+template <int NT = 1> __device__ __forceinline__ B128 mmo(const TabRef &T, const uint32_t *__restrict__ rk, const B128 &in) {
+    B128 o = aes_enc<NT>(T, rk, in);
     o.w[0] ^= in.w[0]; o.w[1] ^= in.w[1]; o.w[2] ^= in.w[2]; o.w[3] ^= in.w[3];
     return o;
 }
@@ -62,8 +89,12 @@ __device__ __forceinline__ void ctr_add(B128 &c, uint32_t k) {
     const uint64_t hi = (((uint64_t)c.w[3] << 32) | c.w[2]) + k;
     c.w[2] = (uint32_t)hi; c.w[3] = (uint32_t)(hi >> 32);
 }
-__device__ __forceinline__ void fill_table(uint32_t *T, const HhTables *__restrict__ tab, uint32_t tid, uint32_t nthreads) {
-    for (uint32_t k = tid; k < T_WORDS; k += nthreads) T[k] = tab->te0[k >> 5];
+template <int NT = 1> __device__ __forceinline__ void fill_table(uint32_t *T, const HhTables *__restrict__ tab, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t k = tid; k < T_WORDS; k += nthreads) {
+        const uint32_t v = tab->te0[k >> 5];
+#pragma unroll
+        for (int t = 0; t < NT; t++) T[t * T_WORDS + k] = rotl(v, NT == 2 ? 16 * t : 8 * t);
+    }
 }
 
 // little-endian loads from byte pointers of any alignment
@@ -130,34 +161,38 @@ __device__ __forceinline__ void sha_of_pi_hex(const uint32_t (&pi)[16], uint32_t
 }
 
 // ------------------------------------------------------------------------------------------ main key
-__global__ __launch_bounds__(256) void k_hh_main(const uint8_t *__restrict__ keys, uint64_t stride, uint32_t depth,
-                                                 const HhTables *__restrict__ tab, uint32_t *__restrict__ dat,
-                                                 uint4 *__restrict__ tpc, uint32_t *__restrict__ buckg,
-                                                 uint8_t *__restrict__ ids, int32_t *__restrict__ status) {
+// One workgroup of 1024 lanes per key chain and one workgroup per CU: the AES tables take NT * 32 KiB of the CU's
+// 160 KiB (four tables up to 1024 buckets, two at 2048), the leaf seeds 16 B each.
+constexpr uint32_t MAIN_THREADS = 1024;
+template <int NT>
+__global__ __launch_bounds__(1024) void k_hh_main(const uint8_t *__restrict__ keys, uint64_t stride, uint32_t depth,
+                                                  const HhTables *__restrict__ tab, uint32_t *__restrict__ dat,
+                                                  uint4 *__restrict__ tpc, uint32_t *__restrict__ buckg,
+                                                  uint8_t *__restrict__ ids, int32_t *__restrict__ status) {
     extern __shared__ uint32_t lds[];
     const uint32_t N = 1u << depth, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint64_t i = blockIdx.x;
     uint32_t *Tall = lds;
-    uint4 *seeds = reinterpret_cast<uint4 *>(lds + T_WORDS);
+    uint4 *seeds = reinterpret_cast<uint4 *>(lds + NT * T_WORDS);
     uint8_t *hdr = reinterpret_cast<uint8_t *>(seeds + N);
-    uint32_t *red = reinterpret_cast<uint32_t *>(hdr + HDR_BYTES);  // [4][256] + 2
-    uint8_t *cbits = reinterpret_cast<uint8_t *>(red + 1026);       // control bit of every node of the current level
+    uint32_t *red = reinterpret_cast<uint32_t *>(hdr + HDR_BYTES);  // 258 sums over the leaves
+    uint8_t *cbits = reinterpret_cast<uint8_t *>(red + 260);        // control bit of every node of the current level
     const HhLayout L(depth);
     const uint8_t *kb = keys + i * stride;
 
-    fill_table(Tall, tab, tid, 256);
-    for (uint32_t k = tid; k < L.sup; k += 256) hdr[k] = kb[k];
-    if (tid < 2) red[1024 + tid] = 0;
+    fill_table<NT>(Tall, tab, tid, MAIN_THREADS);
+    for (uint32_t k = tid; k < L.sup; k += MAIN_THREADS) hdr[k] = kb[k];
+    if (tid < 260) red[tid] = 0;
     __syncthreads();
-    const uint32_t *T = Tall + (tid & 31);
+    const TabRef T = tab_ref(Tall, tid);
     const uint32_t *rk0 = tab->rk[0];
 
     // what bincode, the indexing in eval_all and the asserts of eval_and_check would abort on: the main key's header
     // (thread 0) and every support key's (one per thread)
     int ok_local = 1;
-    for (uint32_t sk = tid; sk < HH_SUPPORT; sk += 256) {
-        const uint8_t *p = kb + L.sup + HH_SUPPORT_LEN * sk;
-        ok_local &= p[0] <= 1 && ldb64(p + 17) == 1 && p[41] <= 1 && p[42] <= 1;
+    if (tid < HH_SUPPORT) {
+        const uint8_t *p = kb + L.sup + HH_SUPPORT_LEN * tid;
+        ok_local = p[0] <= 1 && ldb64(p + 17) == 1 && p[41] <= 1 && p[42] <= 1;
     }
     if (tid == 0) {
         bool ok = hdr[L.key_id] <= 1 && ldb64(hdr + L.cw_len) == depth && ldb64(hdr + L.data_len) == 256 &&
@@ -165,7 +200,7 @@ __global__ __launch_bounds__(256) void k_hh_main(const uint8_t *__restrict__ key
         for (uint32_t l = 0; l < depth; l++) ok = ok && hdr[L.cw + 18 * l + 16] <= 1 && hdr[L.cw + 18 * l + 17] <= 1;
         ok_local &= ok;
         // testing id = AES_vk(id.to_le_bytes()), read little endian (server-hh/src/main.rs:258-259, prg.rs:650-655)
-        const B128 e = aes_enc(T, tab->rk[2], ldb128(hdr));
+        const B128 e = aes_enc<NT>(T, tab->rk[2], ldb128(hdr));
         uint32_t *o = reinterpret_cast<uint32_t *>(ids + 16 * i);
         o[0] = e.w[0]; o[1] = e.w[1]; o[2] = e.w[2]; o[3] = e.w[3];
         const B128 root = ldb128(hdr + L.root);
@@ -177,76 +212,89 @@ __global__ __launch_bounds__(256) void k_hh_main(const uint8_t *__restrict__ key
     const uint64_t leaf0 = i * N;
     if (!all_ok) {
         uint32_t *d = dat + leaf0 * HH_BKT;
-        for (uint64_t k = tid; k < (uint64_t)N * HH_BKT; k += 256) d[k] = 0;
+        for (uint64_t k = tid; k < (uint64_t)N * HH_BKT; k += MAIN_THREADS) d[k] = 0;
         return;
     }
     const bool negate = hdr[L.key_id] != 0;
 
-    // ---- tree: level l has 2^l nodes at seeds[0 .. 2^l); children of node p go to 2p, 2p+1.  In place, from the
-    // last 256-parent chunk down, so that a chunk's children never land on parents still to be read.
+    // ---- tree: level l has 2^l <= 1024 nodes at seeds[0 .. 2^l); the children of node p go to 2p and 2p+1, in place
+    // (every parent is in a register before any child is written)
     for (uint32_t l = 0; l < depth; l++) {
         const B128 cw = ldb128(hdr + L.cw + 18 * l);
         const uint32_t cb0 = hdr[L.cw + 18 * l + 16], cb1 = hdr[L.cw + 18 * l + 17];
-        const uint32_t P = 1u << l;
-#pragma unroll 1
-        for (int c = (int)((P - 1) >> 8); c >= 0; c--) {
-            const uint32_t p = (uint32_t)c * 256 + tid;
-            uint4 s = make_uint4(0, 0, 0, 0);
-            uint32_t bit = 0;
-            if (p < P) { s = seeds[p]; bit = cbits[p]; }
-            __syncthreads();
-            if (p < P) {
-                // expand_direction(true, true): control bits from the seed's two low bits, which are then cleared
-                uint32_t bl = (s.x & 1) == 0, br = (s.x & 2) == 0;
-                B128 c0 = {{s.x & ~3u, s.y, s.z, s.w}};
-                B128 left = mmo(T, rk0, c0);
-                ctr_add(c0, 1);
-                B128 right = mmo(T, rk0, c0);
-                if (bit) {
+        const uint32_t P = 1u << l, p = tid;
+        uint4 s = make_uint4(0, 0, 0, 0);
+        uint32_t bit = 0;
+        if (p < P) { s = seeds[p]; bit = cbits[p]; }
+        __syncthreads();
+        if (p < P) {
+            // expand_direction(true, true): control bits from the seed's two low bits, which are then cleared
+            uint32_t bl = (s.x & 1) == 0, br = (s.x & 2) == 0;
+            B128 c0 = {{s.x & ~3u, s.y, s.z, s.w}};
+            B128 left = mmo<NT>(T, rk0, c0);
+            ctr_add(c0, 1);
+            B128 right = mmo<NT>(T, rk0, c0);
+            if (bit) {
 #pragma unroll
-                    for (int k = 0; k < 4; k++) { left.w[k] ^= cw.w[k]; right.w[k] ^= cw.w[k]; }
-                    bl ^= cb0; br ^= cb1;
-                }
-                seeds[2 * p] = make_uint4(left.w[0], left.w[1], left.w[2], left.w[3]);
-                seeds[2 * p + 1] = make_uint4(right.w[0], right.w[1], right.w[2], right.w[3]);
-                cbits[2 * p] = (uint8_t)bl; cbits[2 * p + 1] = (uint8_t)br;
+                for (int k = 0; k < 4; k++) { left.w[k] ^= cw.w[k]; right.w[k] ^= cw.w[k]; }
+                bl ^= cb0; br ^= cb1;
             }
-            __syncthreads();
+            seeds[2 * p] = make_uint4(left.w[0], left.w[1], left.w[2], left.w[3]);
+            seeds[2 * p + 1] = make_uint4(right.w[0], right.w[1], right.w[2], right.w[3]);
+            cbits[2 * p] = (uint8_t)bl; cbits[2 * p + 1] = (uint8_t)br;
         }
+        __syncthreads();
     }
 
-    // ---- leaf hashes: tilde_pi = mmo_hash2to4(seed, x) with x = IntModN::zero() at EVERY leaf (IntModN::one() has
-    // val 0, common/src/group.rs:448-453, so `x.add(&GIn::one())` never moves), corrected by cs when lsb(seed) = 1
+    // ---- per-leaf pieces that occupy one lane each, as one work list of 2N items:
+    //  items [0, N): tilde_pi = mmo_hash2to4(seed, x) with x = IntModN::zero() at EVERY leaf (IntModN::one() has val 0,
+    //    common/src/group.rs:448-453, so `x.add(&GIn::one())` never moves), corrected by cs when lsb(seed) = 1;
+    //  items [N, 2N): sign_data and ctr of the converted bucket = the first 8 bytes of counter seed+64.
     {
-        B128 cs[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) cs[k] = ldb128(hdr + L.cs + 16 * k);
+        const uint32_t oc0 = ldb32(hdr + L.oc + 1024), oc1 = ldb32(hdr + L.oc + 1028);
+        uint32_t t0 = 0, t1 = 0;
 #pragma unroll 1
-        for (uint32_t x = tid; x < N; x += 256) {
+        for (uint32_t it = tid; it < 2 * N; it += MAIN_THREADS) {
+            const uint32_t x = it & (N - 1);
             const uint4 s = seeds[x];
-            const B128 sd = {{s.x, s.y, s.z, s.w}};
-            const B128 s1 = mmo(T, rk0, sd);
-            const B128 s3 = mmo(T, rk0, s1);
             const uint32_t m = 0u - (s.x & 1);
-            uint4 *o = tpc + (leaf0 + x) * 4;
-            o[0] = make_uint4(tab->cx[0][0] ^ (cs[0].w[0] & m), tab->cx[0][1] ^ (cs[0].w[1] & m), tab->cx[0][2] ^ (cs[0].w[2] & m), tab->cx[0][3] ^ (cs[0].w[3] & m));
-            o[1] = make_uint4(s1.w[0] ^ (cs[1].w[0] & m), s1.w[1] ^ (cs[1].w[1] & m), s1.w[2] ^ (cs[1].w[2] & m), s1.w[3] ^ (cs[1].w[3] & m));
-            o[2] = make_uint4(tab->cx[0][4] ^ (cs[2].w[0] & m), tab->cx[0][5] ^ (cs[2].w[1] & m), tab->cx[0][6] ^ (cs[2].w[2] & m), tab->cx[0][7] ^ (cs[2].w[3] & m));
-            o[3] = make_uint4(s3.w[0] ^ (cs[3].w[0] & m), s3.w[1] ^ (cs[3].w[1] & m), s3.w[2] ^ (cs[3].w[2] & m), s3.w[3] ^ (cs[3].w[3] & m));
+            B128 c = {{s.x, s.y, s.z, s.w}};
+            if (it < N) {
+                const B128 s1 = mmo<NT>(T, rk0, c);
+                const B128 s3 = mmo<NT>(T, rk0, s1);
+                const uint8_t *cs = hdr + L.cs;
+                uint4 *o = tpc + (leaf0 + x) * 4;
+                B128 q = ldb128(cs);
+                o[0] = make_uint4(tab->cx[0][0] ^ (q.w[0] & m), tab->cx[0][1] ^ (q.w[1] & m), tab->cx[0][2] ^ (q.w[2] & m), tab->cx[0][3] ^ (q.w[3] & m));
+                q = ldb128(cs + 16);
+                o[1] = make_uint4(s1.w[0] ^ (q.w[0] & m), s1.w[1] ^ (q.w[1] & m), s1.w[2] ^ (q.w[2] & m), s1.w[3] ^ (q.w[3] & m));
+                q = ldb128(cs + 32);
+                o[2] = make_uint4(tab->cx[0][4] ^ (q.w[0] & m), tab->cx[0][5] ^ (q.w[1] & m), tab->cx[0][6] ^ (q.w[2] & m), tab->cx[0][7] ^ (q.w[3] & m));
+                q = ldb128(cs + 48);
+                o[3] = make_uint4(s3.w[0] ^ (q.w[0] & m), s3.w[1] ^ (q.w[1] & m), s3.w[2] ^ (q.w[2] & m), s3.w[3] ^ (q.w[3] & m));
+            } else {
+                ctr_add(c, 64);
+                const B128 o = mmo<NT>(T, rk0, c);
+                uint32_t a = o.w[0] + (oc0 & m), b = o.w[1] + (oc1 & m);
+                if (negate) { a = 0u - a; b = 0u - b; }
+                *reinterpret_cast<uint2 *>(dat + (leaf0 + x) * HH_BKT + 256) = make_uint2(a, b);
+                t0 += a; t1 += b;
+            }
         }
+        if (t0 | t1) { atomicAdd(&red[256], t0); atomicAdd(&red[257], t1); }
     }
 
-    // ---- convert::<Bucket<u32>>: 1032 bytes = counters seed+0 .. seed+64 (the last half used); one wavefront per
-    // leaf, lane j takes counter j, so a leaf is one 1 KiB coalesced store; the sum over leaves stays in registers
+    // ---- convert::<Bucket<u32>>: 1032 bytes = counters seed+0 .. seed+64 (the last half used, above); one wavefront
+    // per leaf, lane j takes counter j, so a leaf is one 1 KiB coalesced store; the sum over leaves stays in registers
     {
         const B128 oc = ldb128(hdr + L.oc + 16 * lane);
         uint32_t acc[4] = {0, 0, 0, 0};
 #pragma unroll 1
-        for (uint32_t x = wv; x < N; x += 4) {
+        for (uint32_t x = wv; x < N; x += MAIN_THREADS / 64) {
             const uint4 s = seeds[x];
             B128 c = {{s.x, s.y, s.z, s.w}};
             ctr_add(c, lane);
-            B128 o = mmo(T, rk0, c);
+            B128 o = mmo<NT>(T, rk0, c);
             const uint32_t m = 0u - (s.x & 1);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -259,28 +307,10 @@ __global__ __launch_bounds__(256) void k_hh_main(const uint8_t *__restrict__ key
             d[1] = make_uint2(o.w[2], o.w[3]);
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++) red[wv * 256 + 4 * lane + k] = acc[k];
-        // sign_data and ctr: the first 8 bytes of counter seed+64
-        const uint32_t oc0 = ldb32(hdr + L.oc + 1024), oc1 = ldb32(hdr + L.oc + 1028);
-        uint32_t t0 = 0, t1 = 0;
-#pragma unroll 1
-        for (uint32_t x = tid; x < N; x += 256) {
-            const uint4 s = seeds[x];
-            B128 c = {{s.x, s.y, s.z, s.w}};
-            ctr_add(c, 64);
-            const B128 o = mmo(T, rk0, c);
-            const uint32_t m = 0u - (s.x & 1);
-            uint32_t a = o.w[0] + (oc0 & m), b = o.w[1] + (oc1 & m);
-            if (negate) { a = 0u - a; b = 0u - b; }
-            *reinterpret_cast<uint2 *>(dat + (leaf0 + x) * HH_BKT + 256) = make_uint2(a, b);
-            t0 += a; t1 += b;
-        }
-        atomicAdd(&red[1024], t0);
-        atomicAdd(&red[1025], t1);
+        for (int k = 0; k < 4; k++) atomicAdd(&red[4 * lane + k], acc[k]);
     }
     __syncthreads();
-    buckg[i * HH_BKT + tid] = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid];
-    if (tid < 2) buckg[i * HH_BKT + 256 + tid] = red[1024 + tid];
+    if (tid < HH_BKT) buckg[i * HH_BKT + tid] = red[tid];
 }
 
 // ------------------------------------------------------------------------------------------ support keys
@@ -292,7 +322,7 @@ __global__ __launch_bounds__(256) void k_hh_support(const uint8_t *__restrict__ 
     const uint32_t tid = threadIdx.x;
     fill_table(Tall, tab, tid, 256);
     __syncthreads();
-    const uint32_t *T = Tall + (tid & 31);
+    const TabRef T = tab_ref(Tall, tid);
     const uint64_t g = (uint64_t)blockIdx.x * 256 + tid;
     if (g >= (uint64_t)n * HH_SUPPORT) return;
     const uint64_t i = g / HH_SUPPORT;
@@ -350,47 +380,45 @@ __global__ __launch_bounds__(256) void k_hh_support(const uint8_t *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------ proof chain of the main key
-__global__ __launch_bounds__(64) void k_hh_chain(const uint8_t *__restrict__ keys, uint64_t stride, uint32_t n, uint32_t depth,
-                                                 const HhTables *__restrict__ tab, const uint4 *__restrict__ tpc,
-                                                 uint32_t *__restrict__ proofblk, const int32_t *__restrict__ status) {
+// pi <- pi ^ H'(pi ^ tilde_pi_x) for x = 0 .. N-1.  H' (mmo_hash4to4) hashes its four 16-byte blocks independently, so
+// the chain is four independent block chains: four lanes per key chain, no exchange until the final SHA-256.  A step is
+// one AES on the critical path and the kernel is bound by the issue latency of a lone wavefront, not by throughput.
+__global__ __launch_bounds__(256) void k_hh_chain(const uint8_t *__restrict__ keys, uint64_t stride, uint32_t n, uint32_t depth,
+                                                  const HhTables *__restrict__ tab, const uint4 *__restrict__ tpc,
+                                                  uint32_t *__restrict__ proofblk, const int32_t *__restrict__ status) {
     __shared__ uint32_t Tall[T_WORDS];
     const uint32_t tid = threadIdx.x;
-    fill_table(Tall, tab, tid, 64);
+    fill_table(Tall, tab, tid, 256);
     __syncthreads();
-    const uint32_t *T = Tall + (tid & 31);
-    const uint64_t i = (uint64_t)blockIdx.x * 64 + tid;
-    if (i >= n || status[i] != 0) return;
+    const TabRef T = tab_ref(Tall, tid);
+    const uint64_t g = (uint64_t)blockIdx.x * 256 + tid;
+    const uint64_t i = g >> 2;
+    const uint32_t b = (uint32_t)g & 3;
+    const bool live = i < n && status[i] == 0;
     const HhLayout L(depth);
-    const uint8_t *p = keys + i * stride + L.cs;
     const uint32_t *rk1 = tab->rk[1];
-    uint32_t pi[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) pi[k] = ldb32(p + 4 * k);
     const uint32_t N = 1u << depth;
-    const uint4 *tp = tpc + i * N * 4;
-    uint4 nx[4];
-#pragma unroll
-    for (int b = 0; b < 4; b++) nx[b] = tp[b];
+    B128 pi = {{0, 0, 0, 0}};
+    if (live) {
+        pi = ldb128(keys + i * stride + L.cs + 16 * b);
+        const uint4 *tp = tpc + i * N * 4 + b;
+        uint4 nx = tp[0];
 #pragma unroll 1
-    for (uint32_t x = 0; x < N; x++) {
-        B128 hin[4];
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            hin[b].w[0] = pi[4 * b] ^ nx[b].x; hin[b].w[1] = pi[4 * b + 1] ^ nx[b].y;
-            hin[b].w[2] = pi[4 * b + 2] ^ nx[b].z; hin[b].w[3] = pi[4 * b + 3] ^ nx[b].w;
-        }
-        if (x + 1 < N) {
-#pragma unroll
-            for (int b = 0; b < 4; b++) nx[b] = tp[(x + 1) * 4 + b];
-        }
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const B128 ho = mmo(T, rk1, hin[b]);
-#pragma unroll
-            for (int k = 0; k < 4; k++) pi[4 * b + k] ^= ho.w[k];
+        for (uint32_t x = 0; x < N; x++) {
+            const B128 hin = {{pi.w[0] ^ nx.x, pi.w[1] ^ nx.y, pi.w[2] ^ nx.z, pi.w[3] ^ nx.w}};
+            if (x + 1 < N) nx = tp[(x + 1) * 4];
+            const B128 ho = mmo(T, rk1, hin);
+            pi.w[0] ^= ho.w[0]; pi.w[1] ^= ho.w[1]; pi.w[2] ^= ho.w[2]; pi.w[3] ^= ho.w[3];
         }
     }
-    sha_of_pi_hex(pi, proofblk + i * (HH_SUPPORT + 1) * 16);
+    // gather the four blocks in the first lane of the quad
+    uint32_t all[16];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) all[4 * q + k] = __shfl(pi.w[k], (int)((tid & 60) + q), 64);
+    }
+    if (live && b == 0) sha_of_pi_hex(all, proofblk + i * (HH_SUPPORT + 1) * 16);
 }
 
 // ------------------------------------------------------------------------------------------ folding and the tag
@@ -473,8 +501,9 @@ __global__ __launch_bounds__(64) void k_hh_final(const uint8_t *__restrict__ key
 
 }  // namespace
 
+static int hh_main_tables(uint32_t depth) { return depth <= 10 ? 4 : 2; }
 size_t hh_main_lds_bytes(uint32_t depth) {
-    return 4 * (size_t)T_WORDS + 16 * ((size_t)1 << depth) + HDR_BYTES + 4 * 1026 + ((size_t)1 << depth) + 16;
+    return 4 * (size_t)T_WORDS * hh_main_tables(depth) + 16 * ((size_t)1 << depth) + HDR_BYTES + 4 * 260 + ((size_t)1 << depth) + 16;
 }
 
 int launch_hh_eval(const uint8_t *d_keys, uint64_t stride, uint32_t n, uint32_t depth, const HhTables *d_tab,
@@ -482,17 +511,14 @@ int launch_hh_eval(const uint8_t *d_keys, uint64_t stride, uint32_t n, uint32_t 
                    hipStream_t stream) {
     if (!n) return 0;
     const size_t lds = hh_main_lds_bytes(depth);
-    static size_t lds_allowed = 64 * 1024;
-    if (lds > lds_allowed) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_hh_main), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        lds_allowed = lds;
-    }
-    hipLaunchKernelGGL(k_hh_main, dim3(n), dim3(256), lds, stream, d_keys, stride, depth, d_tab, d_dat, w.tpc, w.buckg, d_ids, d_status);
+    auto kmain = hh_main_tables(depth) == 4 ? k_hh_main<4> : k_hh_main<2>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kmain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kmain, dim3(n), dim3(MAIN_THREADS), lds, stream, d_keys, stride, depth, d_tab, d_dat, w.tpc, w.buckg, d_ids, d_status);
     const uint64_t sup_threads = (uint64_t)n * HH_SUPPORT;
     hipLaunchKernelGGL(k_hh_support, dim3((uint32_t)((sup_threads + 255) / 256)), dim3(256), 0, stream, d_keys, stride, n, depth, d_tab,
                        w.proofblk, w.supd, d_status);
-    hipLaunchKernelGGL(k_hh_chain, dim3((n + 63) / 64), dim3(64), 0, stream, d_keys, stride, n, depth, d_tab, w.tpc, w.proofblk, d_status);
+    hipLaunchKernelGGL(k_hh_chain, dim3((uint32_t)((4ull * n + 255) / 256)), dim3(256), 0, stream, d_keys, stride, n, depth, d_tab, w.tpc, w.proofblk, d_status);
     hipLaunchKernelGGL(k_hh_final, dim3((n + 63) / 64), dim3(64), 0, stream, d_keys, stride, n, depth, w.proofblk, w.supd, w.buckg, d_tags,
                        d_status);
     return (int)hipGetLastError();
