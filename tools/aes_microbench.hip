@@ -34,27 +34,33 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t seed) {
 }
 
 // LDS: CH independent lookup chains per lane, each x <- T[(x & 0xff) * 32 + lane % 32]
-template <int CH>
+template <int CH, int EXTRA = 0>
 __global__ void __launch_bounds__(256) klds(uint32_t *out, uint32_t seed) {
     __shared__ uint32_t T[256 * 32];
     for (uint32_t k = threadIdx.x; k < 256 * 32; k += 256) T[k] = (k >> 5) * 0x01010101u ^ (k * 2654435761u >> 7);
     __syncthreads();
     typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
     const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t *)T + 4 * (threadIdx.x & 31);
-    uint32_t x[CH];
+    uint32_t x[CH], y[8];
 #pragma unroll
     for (int i = 0; i < CH; i++) x[i] = seed * (i + 3) + threadIdx.x * 7;
+#pragma unroll
+    for (int i = 0; i < 8; i++) y[i] = seed + i;
     for (int it = 0; it < ITERS; it++) {
 #pragma unroll
         for (int i = 0; i < CH; i++) {
             uint32_t sh;
             asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(sh) : "v"(7u), "v"(x[i]));
             x[i] = *(lds_cu32 *)(uintptr_t)(base + sh);
+#pragma unroll
+            for (int e = 0; e < EXTRA; e++) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(y[(i + e) & 7]) : "v"(seed));
         }
     }
     uint32_t r = 0;
 #pragma unroll
     for (int i = 0; i < CH; i++) r ^= x[i];
+#pragma unroll
+    for (int i = 0; i < 8; i++) r ^= y[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
@@ -80,6 +86,9 @@ int main() {
         R(5, "v_or_b32"); R(6, "v_and_b32 literal"); R(7, "v_add_u32_sdwa BYTE_2"); R(8, "v_perm_b32"); R(9, "v_mad_u32_u24");
         run("ds_read_b32 table, 8 chains", [&] { hipLaunchKernelGGL(klds<8>, dim3(blocks), dim3(256), 0, 0, (uint32_t *)out, 12345u); }, ops);
         run("ds_read_b32 table, 16 chains", [&] { hipLaunchKernelGGL(klds<16>, dim3(blocks), dim3(256), 0, 0, (uint32_t *)out, 12345u); }, ops * 2);
+        run("  + 1 full-rate VALU per read", [&] { hipLaunchKernelGGL((klds<16, 1>), dim3(blocks), dim3(256), 0, 0, (uint32_t *)out, 12345u); }, ops * 2);
+        run("  + 2 full-rate VALU per read", [&] { hipLaunchKernelGGL((klds<16, 2>), dim3(blocks), dim3(256), 0, 0, (uint32_t *)out, 12345u); }, ops * 2);
+        run("  + 4 full-rate VALU per read", [&] { hipLaunchKernelGGL((klds<16, 4>), dim3(blocks), dim3(256), 0, 0, (uint32_t *)out, 12345u); }, ops * 2);
     }
     return 0;
 }

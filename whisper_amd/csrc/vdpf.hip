@@ -29,26 +29,40 @@ struct B128 { uint32_t w[4]; };
 __device__ __forceinline__ uint32_t rotl(uint32_t v, int n) { return __builtin_rotateleft32(v, n); }
 
 // AES-128 with NT tables in LDS.  NT = 1: Te0, three rotates per column.  NT = 2: Te0 and Te0 <<< 16, one rotate per
-// column.  NT = 4: Te0 <<< 8t, none.  Table t starts t * 32 KiB after table 0.  Addresses are formed as integers --
-// (byte << 7) + lane address, one v_bfe + one v_lshl_add per read, the table offset in the instruction's immediate --
-// and the column is two three-input XORs (v_bitop3).  rk = 44 round-key words (uniform).
+// column.  NT = 4: Te0 <<< 8t, none.  rk = 44 round-key words (uniform).
+//
+// Measured on MI355X (tools/aes_microbench.hip, profiles/r1_aes_microbench.txt): a wavefront's ds_read_b32 and its VALU
+// instructions do not overlap -- every extra VALU instruction per table read costs its full issue time -- so the cost
+// of a table read is the issue time of the instructions that form its address plus the read itself: v_bfe + v_lshl_add
+// 4.2 + 4.2 cycles, SDWA shift + add 4.2 + 2.3, v_perm_b32 4.2; the read 2.6; a three-input XOR 2.3.
+//   NT = 1 (small kernels): 32 KiB, word index entry*32 + lane%32, address = SDWA byte shift + add.
+//   NT = 2, 4: an entry row is 256 bytes -- table (t & 1) in its lower / upper 128 bytes, 32 lane copies each -- and
+//   tables 2, 3 sit 64 KiB higher, so the whole address is ONE v_perm_b32: byte 0 = this lane's offset, byte 1 = the
+//   state byte, byte 2 = the 64 KiB region, and the half-row is the instruction's immediate offset.  The tables must
+//   start at LDS address 0 (the kernel has no other static LDS).
 typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
-struct TabRef { uint32_t a, b; };  // byte address of this lane's copy of entry 0: a = table 0, b = table 2 (NT = 4)
+struct TabRef { uint32_t a, b; };  // NT = 1: byte address of this lane's copy of entry 0.  NT = 2, 4: v_perm source words
 __device__ __forceinline__ TabRef tab_ref(const uint32_t *tables, uint32_t tid) {
     const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t *)tables + 4 * (tid & 31);
-    return TabRef{base, base + 8 * T_WORDS};
+    return TabRef{base, base | 0x10000u};
 }
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 template <int NT> __device__ __forceinline__ uint32_t te(const TabRef &R, int t, uint32_t x, int sh) {
     static_assert(NT == 1 || NT == 2 || NT == 4, "table count");
-    uint32_t byte;
-    if (sh == 24) byte = x >> 24;
-    else if (sh == 0) asm("v_bfe_u32 %0, %1, 0, 8" : "=v"(byte) : "v"(x));  // kept as one instruction: (x & 0xff) << 7 would
-    else byte = __builtin_amdgcn_ubfe(x, sh, 8);                            // be rewritten into shift, mask and add
-    const uint32_t idx = byte << 7;
-    if (NT == 4) return *(lds_cu32 *)(uintptr_t)((t < 2 ? R.a : R.b) + idx + (t & 1) * 4 * T_WORDS);
-    if (NT == 2) return *(lds_cu32 *)(uintptr_t)(R.a + idx + (t >> 1) * 4 * T_WORDS);   // t = 0 or 2
-    return *(lds_cu32 *)(uintptr_t)(R.a + idx);
+    if (NT == 1) {
+        // byte select and shift in one (half-rate) SDWA instruction; v_bfe_u32 + v_lshl_add_u32 would be two
+        uint32_t idx;
+        if (sh == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(idx) : "v"(7u), "v"(x));
+        else if (sh == 8) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(idx) : "v"(7u), "v"(x));
+        else if (sh == 16) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(idx) : "v"(7u), "v"(x));
+        else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(idx) : "v"(7u), "v"(x));
+        return *(lds_cu32 *)(uintptr_t)(R.a + idx);
+    }
+    // selector bytes, low to high: lane word byte 0, state byte sh/8 (source 0 = bytes 4..7), lane word byte 2, zero
+    const uint32_t sel = 0x0c020000u | ((4u + sh / 8) << 8);
+    const int tt = NT == 4 ? t : t >> 1;   // NT = 2 holds tables 0 and 2 in the two half-rows of region 0
+    const uint32_t addr = __builtin_amdgcn_perm(x, tt < 2 ? R.a : R.b, sel);
+    return *(lds_cu32 *)(uintptr_t)(addr + (tt & 1) * 128);
 }
 template <int NT> __device__ __forceinline__ uint32_t aes_col(const TabRef &R, uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t k) {
     if (NT == 4) return xor3(xor3(te<4>(R, 0, a, 0), te<4>(R, 1, b, 8), te<4>(R, 2, c, 16)), te<4>(R, 3, d, 24), k);
@@ -84,6 +98,23 @@ template <int NT = 1> __device__ __forceinline__ B128 mmo(const TabRef &T, const
     o.w[0] ^= in.w[0]; o.w[1] ^= in.w[1]; o.w[2] ^= in.w[2]; o.w[3] ^= in.w[3];
     return o;
 }
+// two independent blocks, round by round, so that both blocks' table reads are in flight together
+template <int NT> __device__ __forceinline__ void mmo2(const TabRef &R, const uint32_t *__restrict__ rk, const B128 &ia, const B128 &ib, B128 &oa, B128 &ob) {
+    uint32_t a0 = ia.w[0] ^ rk[0], a1 = ia.w[1] ^ rk[1], a2 = ia.w[2] ^ rk[2], a3 = ia.w[3] ^ rk[3];
+    uint32_t b0 = ib.w[0] ^ rk[0], b1 = ib.w[1] ^ rk[1], b2 = ib.w[2] ^ rk[2], b3 = ib.w[3] ^ rk[3];
+#pragma unroll
+    for (int r = 1; r < 10; r++) {
+        const uint32_t t0 = aes_col<NT>(R, a0, a1, a2, a3, rk[4 * r]), u0 = aes_col<NT>(R, b0, b1, b2, b3, rk[4 * r]);
+        const uint32_t t1 = aes_col<NT>(R, a1, a2, a3, a0, rk[4 * r + 1]), u1 = aes_col<NT>(R, b1, b2, b3, b0, rk[4 * r + 1]);
+        const uint32_t t2 = aes_col<NT>(R, a2, a3, a0, a1, rk[4 * r + 2]), u2 = aes_col<NT>(R, b2, b3, b0, b1, rk[4 * r + 2]);
+        const uint32_t t3 = aes_col<NT>(R, a3, a0, a1, a2, rk[4 * r + 3]), u3 = aes_col<NT>(R, b3, b0, b1, b2, rk[4 * r + 3]);
+        a0 = t0; a1 = t1; a2 = t2; a3 = t3; b0 = u0; b1 = u1; b2 = u2; b3 = u3;
+    }
+    oa.w[0] = aes_last<NT>(R, a0, a1, a2, a3, rk[40]) ^ ia.w[0]; ob.w[0] = aes_last<NT>(R, b0, b1, b2, b3, rk[40]) ^ ib.w[0];
+    oa.w[1] = aes_last<NT>(R, a1, a2, a3, a0, rk[41]) ^ ia.w[1]; ob.w[1] = aes_last<NT>(R, b1, b2, b3, b0, rk[41]) ^ ib.w[1];
+    oa.w[2] = aes_last<NT>(R, a2, a3, a0, a1, rk[42]) ^ ia.w[2]; ob.w[2] = aes_last<NT>(R, b2, b3, b0, b1, rk[42]) ^ ib.w[2];
+    oa.w[3] = aes_last<NT>(R, a3, a0, a1, a2, rk[43]) ^ ia.w[3]; ob.w[3] = aes_last<NT>(R, b3, b0, b1, b2, rk[43]) ^ ib.w[3];
+}
 // inc_be (prg.rs:449-452): the counter's upper 64-bit lane
 __device__ __forceinline__ void ctr_add(B128 &c, uint32_t k) {
     const uint64_t hi = (((uint64_t)c.w[3] << 32) | c.w[2]) + k;
@@ -91,9 +122,11 @@ __device__ __forceinline__ void ctr_add(B128 &c, uint32_t k) {
 }
 template <int NT = 1> __device__ __forceinline__ void fill_table(uint32_t *T, const HhTables *__restrict__ tab, uint32_t tid, uint32_t nthreads) {
     for (uint32_t k = tid; k < T_WORDS; k += nthreads) {
-        const uint32_t v = tab->te0[k >> 5];
+        const uint32_t e = k >> 5, rep = k & 31, v = tab->te0[e];
+        if (NT == 1) T[k] = v;
 #pragma unroll
-        for (int t = 0; t < NT; t++) T[t * T_WORDS + k] = rotl(v, NT == 2 ? 16 * t : 8 * t);
+        for (int t = 0; t < (NT == 1 ? 0 : NT); t++)   // row of 64 words per entry, half-row (t & 1), region t >> 1
+            T[(t >> 1) * 16384 + e * 64 + (t & 1) * 32 + rep] = rotl(v, NT == 2 ? 16 * t : 8 * t);
     }
 }
 
@@ -161,156 +194,211 @@ __device__ __forceinline__ void sha_of_pi_hex(const uint32_t (&pi)[16], uint32_t
 }
 
 // ------------------------------------------------------------------------------------------ main key
-// One workgroup of 1024 lanes per key chain and one workgroup per CU: the AES tables take NT * 32 KiB of the CU's
-// 160 KiB (four tables up to 1024 buckets, two at 2048), the leaf seeds 16 B each.
-constexpr uint32_t MAIN_THREADS = 1024;
+// Persistent workgroups of 1024 lanes, one per CU, each walking over key chains blockIdx.x, + gridDim.x, ...  The AES
+// tables take NT * 32 KiB of the CU's 160 KiB (four tables up to 512 buckets, two above).  The last wavefront is the
+// PRODUCER: while the other fifteen turn key chain k into buckets it copies and checks the header of key chain k + G,
+// computes its testing id and expands its tree into the other seed buffer -- work that is a chain of AES latencies
+// (two per level and 64-node pass) and would otherwise leave the CU idle.  One barrier per key chain.
+constexpr uint32_t MAIN_THREADS = 1024, CONSUMERS = MAIN_THREADS - 64;
+
+// header copy, checks, testing id and tree of key chain i into (hdr, seeds); one wavefront, no workgroup barrier inside
 template <int NT>
-__global__ __launch_bounds__(1024) void k_hh_main(const uint8_t *__restrict__ keys, uint64_t stride, uint32_t depth,
-                                                  const HhTables *__restrict__ tab, uint32_t *__restrict__ dat,
-                                                  uint4 *__restrict__ tpc, uint32_t *__restrict__ buckg,
-                                                  uint8_t *__restrict__ ids, int32_t *__restrict__ status) {
-    extern __shared__ uint32_t lds[];
-    const uint32_t N = 1u << depth, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint64_t i = blockIdx.x;
-    uint32_t *Tall = lds;
-    uint4 *seeds = reinterpret_cast<uint4 *>(lds + NT * T_WORDS);
-    uint8_t *hdr = reinterpret_cast<uint8_t *>(seeds + N);
-    uint32_t *red = reinterpret_cast<uint32_t *>(hdr + HDR_BYTES);  // 258 sums over the leaves
-    uint8_t *cbits = reinterpret_cast<uint8_t *>(red + 260);        // control bit of every node of the current level
+__device__ __forceinline__ bool hh_prepare(const TabRef &T, const HhTables *__restrict__ tab, const uint8_t *kb, uint32_t depth,
+                                            uint32_t lane, uint8_t *hdr, uint4 *seeds, uint8_t *cbits, uint8_t *id_out) {
     const HhLayout L(depth);
-    const uint8_t *kb = keys + i * stride;
-
-    fill_table<NT>(Tall, tab, tid, MAIN_THREADS);
-    for (uint32_t k = tid; k < L.sup; k += MAIN_THREADS) hdr[k] = kb[k];
-    if (tid < 260) red[tid] = 0;
-    __syncthreads();
-    const TabRef T = tab_ref(Tall, tid);
     const uint32_t *rk0 = tab->rk[0];
-
-    // what bincode, the indexing in eval_all and the asserts of eval_and_check would abort on: the main key's header
-    // (thread 0) and every support key's (one per thread)
-    int ok_local = 1;
-    if (tid < HH_SUPPORT) {
-        const uint8_t *p = kb + L.sup + HH_SUPPORT_LEN * tid;
-        ok_local = p[0] <= 1 && ldb64(p + 17) == 1 && p[41] <= 1 && p[42] <= 1;
+    for (uint32_t k = lane; k < L.sup; k += 64) hdr[k] = kb[k];
+    // what bincode, the indexing in eval_all and the asserts of eval_and_check would abort on: every support key's
+    // header and the main key's
+    bool ok = true;
+    for (uint32_t sk = lane; sk < HH_SUPPORT; sk += 64) {
+        const uint8_t *p = kb + L.sup + HH_SUPPORT_LEN * sk;
+        ok = ok && p[0] <= 1 && ldb64(p + 17) == 1 && p[41] <= 1 && p[42] <= 1;
     }
-    if (tid == 0) {
-        bool ok = hdr[L.key_id] <= 1 && ldb64(hdr + L.cw_len) == depth && ldb64(hdr + L.data_len) == 256 &&
-                  ldb64(hdr + L.sup_len) == HH_SUPPORT;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane == 0) {
+        ok = ok && hdr[L.key_id] <= 1 && ldb64(hdr + L.cw_len) == depth && ldb64(hdr + L.data_len) == 256 &&
+             ldb64(hdr + L.sup_len) == HH_SUPPORT;
         for (uint32_t l = 0; l < depth; l++) ok = ok && hdr[L.cw + 18 * l + 16] <= 1 && hdr[L.cw + 18 * l + 17] <= 1;
-        ok_local &= ok;
         // testing id = AES_vk(id.to_le_bytes()), read little endian (server-hh/src/main.rs:258-259, prg.rs:650-655)
         const B128 e = aes_enc<NT>(T, tab->rk[2], ldb128(hdr));
-        uint32_t *o = reinterpret_cast<uint32_t *>(ids + 16 * i);
+        uint32_t *o = reinterpret_cast<uint32_t *>(id_out);
         o[0] = e.w[0]; o[1] = e.w[1]; o[2] = e.w[2]; o[3] = e.w[3];
         const B128 root = ldb128(hdr + L.root);
         seeds[0] = make_uint4(root.w[0], root.w[1], root.w[2], root.w[3]);
         cbits[0] = hdr[L.key_id];
     }
-    const int all_ok = __syncthreads_and(ok_local);
-    if (tid == 0) status[i] = all_ok ? 0 : HH_ERR_KEY_FORMAT;
-    const uint64_t leaf0 = i * N;
-    if (!all_ok) {
-        uint32_t *d = dat + leaf0 * HH_BKT;
-        for (uint64_t k = tid; k < (uint64_t)N * HH_BKT; k += MAIN_THREADS) d[k] = 0;
-        return;
-    }
-    const bool negate = hdr[L.key_id] != 0;
-
-    // ---- tree: level l has 2^l <= 1024 nodes at seeds[0 .. 2^l); the children of node p go to 2p and 2p+1, in place
-    // (every parent is in a register before any child is written)
+    ok = __all(ok);
+    if (!ok) return false;
+    // tree: level l has 2^l nodes at seeds[0 .. 2^l); the children of node p go to 2p and 2p+1, in place, from the last
+    // 64-parent pass down so that children never land on parents still to be read
+#ifdef HH_EXP_NO_TREE
+    for (uint32_t l = 0; l < 1; l++) {
+#else
     for (uint32_t l = 0; l < depth; l++) {
+#endif
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const B128 cw = ldb128(hdr + L.cw + 18 * l);
         const uint32_t cb0 = hdr[L.cw + 18 * l + 16], cb1 = hdr[L.cw + 18 * l + 17];
-        const uint32_t P = 1u << l, p = tid;
-        uint4 s = make_uint4(0, 0, 0, 0);
-        uint32_t bit = 0;
-        if (p < P) { s = seeds[p]; bit = cbits[p]; }
-        __syncthreads();
-        if (p < P) {
-            // expand_direction(true, true): control bits from the seed's two low bits, which are then cleared
-            uint32_t bl = (s.x & 1) == 0, br = (s.x & 2) == 0;
-            B128 c0 = {{s.x & ~3u, s.y, s.z, s.w}};
-            B128 left = mmo<NT>(T, rk0, c0);
-            ctr_add(c0, 1);
-            B128 right = mmo<NT>(T, rk0, c0);
-            if (bit) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) { left.w[k] ^= cw.w[k]; right.w[k] ^= cw.w[k]; }
-                bl ^= cb0; br ^= cb1;
-            }
-            seeds[2 * p] = make_uint4(left.w[0], left.w[1], left.w[2], left.w[3]);
-            seeds[2 * p + 1] = make_uint4(right.w[0], right.w[1], right.w[2], right.w[3]);
-            cbits[2 * p] = (uint8_t)bl; cbits[2 * p + 1] = (uint8_t)br;
-        }
-        __syncthreads();
-    }
-
-    // ---- per-leaf pieces that occupy one lane each, as one work list of 2N items:
-    //  items [0, N): tilde_pi = mmo_hash2to4(seed, x) with x = IntModN::zero() at EVERY leaf (IntModN::one() has val 0,
-    //    common/src/group.rs:448-453, so `x.add(&GIn::one())` never moves), corrected by cs when lsb(seed) = 1;
-    //  items [N, 2N): sign_data and ctr of the converted bucket = the first 8 bytes of counter seed+64.
-    {
-        const uint32_t oc0 = ldb32(hdr + L.oc + 1024), oc1 = ldb32(hdr + L.oc + 1028);
-        uint32_t t0 = 0, t1 = 0;
+        const uint32_t P = 1u << l;
 #pragma unroll 1
-        for (uint32_t it = tid; it < 2 * N; it += MAIN_THREADS) {
-            const uint32_t x = it & (N - 1);
-            const uint4 s = seeds[x];
-            const uint32_t m = 0u - (s.x & 1);
-            B128 c = {{s.x, s.y, s.z, s.w}};
-            if (it < N) {
-                const B128 s1 = mmo<NT>(T, rk0, c);
-                const B128 s3 = mmo<NT>(T, rk0, s1);
-                const uint8_t *cs = hdr + L.cs;
-                uint4 *o = tpc + (leaf0 + x) * 4;
-                B128 q = ldb128(cs);
-                o[0] = make_uint4(tab->cx[0][0] ^ (q.w[0] & m), tab->cx[0][1] ^ (q.w[1] & m), tab->cx[0][2] ^ (q.w[2] & m), tab->cx[0][3] ^ (q.w[3] & m));
-                q = ldb128(cs + 16);
-                o[1] = make_uint4(s1.w[0] ^ (q.w[0] & m), s1.w[1] ^ (q.w[1] & m), s1.w[2] ^ (q.w[2] & m), s1.w[3] ^ (q.w[3] & m));
-                q = ldb128(cs + 32);
-                o[2] = make_uint4(tab->cx[0][4] ^ (q.w[0] & m), tab->cx[0][5] ^ (q.w[1] & m), tab->cx[0][6] ^ (q.w[2] & m), tab->cx[0][7] ^ (q.w[3] & m));
-                q = ldb128(cs + 48);
-                o[3] = make_uint4(s3.w[0] ^ (q.w[0] & m), s3.w[1] ^ (q.w[1] & m), s3.w[2] ^ (q.w[2] & m), s3.w[3] ^ (q.w[3] & m));
-            } else {
-                ctr_add(c, 64);
-                const B128 o = mmo<NT>(T, rk0, c);
-                uint32_t a = o.w[0] + (oc0 & m), b = o.w[1] + (oc1 & m);
-                if (negate) { a = 0u - a; b = 0u - b; }
-                *reinterpret_cast<uint2 *>(dat + (leaf0 + x) * HH_BKT + 256) = make_uint2(a, b);
-                t0 += a; t1 += b;
+        for (int c = (int)((P - 1) >> 6); c >= 0; c--) {
+            const uint32_t p = (uint32_t)c * 64 + lane;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (p < P) {
+                const uint4 s = seeds[p];
+                const uint32_t bit = cbits[p];
+                // expand_direction(true, true): control bits from the seed's two low bits, which are then cleared
+                uint32_t bl = (s.x & 1) == 0, br = (s.x & 2) == 0;
+                B128 c0 = {{s.x & ~3u, s.y, s.z, s.w}};
+                B128 left = mmo<NT>(T, rk0, c0);
+                ctr_add(c0, 1);
+                B128 right = mmo<NT>(T, rk0, c0);
+                if (bit) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { left.w[k] ^= cw.w[k]; right.w[k] ^= cw.w[k]; }
+                    bl ^= cb0; br ^= cb1;
+                }
+                seeds[2 * p] = make_uint4(left.w[0], left.w[1], left.w[2], left.w[3]);
+                seeds[2 * p + 1] = make_uint4(right.w[0], right.w[1], right.w[2], right.w[3]);
+                cbits[2 * p] = (uint8_t)bl; cbits[2 * p + 1] = (uint8_t)br;
             }
         }
-        if (t0 | t1) { atomicAdd(&red[256], t0); atomicAdd(&red[257], t1); }
     }
+    return true;
+}
 
-    // ---- convert::<Bucket<u32>>: 1032 bytes = counters seed+0 .. seed+64 (the last half used, above); one wavefront
-    // per leaf, lane j takes counter j, so a leaf is one 1 KiB coalesced store; the sum over leaves stays in registers
-    {
-        const B128 oc = ldb128(hdr + L.oc + 16 * lane);
-        uint32_t acc[4] = {0, 0, 0, 0};
-#pragma unroll 1
-        for (uint32_t x = wv; x < N; x += MAIN_THREADS / 64) {
-            const uint4 s = seeds[x];
-            B128 c = {{s.x, s.y, s.z, s.w}};
-            ctr_add(c, lane);
-            B128 o = mmo<NT>(T, rk0, c);
-            const uint32_t m = 0u - (s.x & 1);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                o.w[k] += oc.w[k] & m;
-                if (negate) o.w[k] = 0u - o.w[k];
-                acc[k] += o.w[k];
-            }
-            uint2 *d = reinterpret_cast<uint2 *>(dat + (leaf0 + x) * HH_BKT + 4 * lane);  // 8-byte aligned only
-            d[0] = make_uint2(o.w[0], o.w[1]);
-            d[1] = make_uint2(o.w[2], o.w[3]);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) atomicAdd(&red[4 * lane + k], acc[k]);
+template <int NT>
+__global__ __launch_bounds__(1024) void k_hh_main(const uint8_t *__restrict__ keys, uint64_t stride, uint32_t n, uint32_t depth,
+                                                  const HhTables *__restrict__ tab, uint32_t *__restrict__ dat,
+                                                  uint4 *__restrict__ tpc, uint32_t *__restrict__ buckg,
+                                                  uint8_t *__restrict__ ids, int32_t *__restrict__ status) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t N = 1u << depth, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t *Tall = lds;
+    uint4 *seeds_b = reinterpret_cast<uint4 *>(lds + NT * T_WORDS);     // [2][N]
+    uint8_t *hdr_b = reinterpret_cast<uint8_t *>(seeds_b + 2 * N);       // [2][HDR_BYTES]
+    uint32_t *red_b = reinterpret_cast<uint32_t *>(hdr_b + 2 * HDR_BYTES);  // [2][260] sums over the leaves
+    uint32_t *okf = red_b + 520;                                          // [2]
+    uint8_t *cbits = reinterpret_cast<uint8_t *>(okf + 4);                // control bits of the level being expanded
+    const HhLayout L(depth);
+    const bool producer = wv == MAIN_THREADS / 64 - 1;
+
+    fill_table<NT>(Tall, tab, tid, MAIN_THREADS);
+    if (tid < 520) red_b[tid] = 0;
+    __syncthreads();
+    const TabRef T = tab_ref(Tall, tid);
+    const uint32_t *rk0 = tab->rk[0];
+    const uint32_t G = gridDim.x;
+
+    if (producer) {
+        const uint32_t k = blockIdx.x;
+        const bool ok = hh_prepare<NT>(T, tab, keys + (uint64_t)k * stride, depth, lane, hdr_b, seeds_b, cbits, ids + 16ull * k);
+        if (lane == 0) { okf[0] = ok; status[k] = ok ? 0 : HH_ERR_KEY_FORMAT; }
     }
     __syncthreads();
-    if (tid < HH_BKT) buckg[i * HH_BKT + tid] = red[tid];
+
+    uint32_t cur = 0;
+#pragma unroll 1
+    for (uint32_t k = blockIdx.x; k < n; k += G, cur ^= 1) {
+        uint4 *seeds = seeds_b + cur * N;
+        const uint8_t *hdr = hdr_b + cur * HDR_BYTES;
+        uint32_t *red = red_b + cur * 260;
+        const uint64_t leaf0 = (uint64_t)k * N;
+        if (producer) {
+            const uint32_t kn = k + G;
+            if (kn < n) {
+                const bool ok = hh_prepare<NT>(T, tab, keys + (uint64_t)kn * stride, depth, lane, hdr_b + (cur ^ 1) * HDR_BYTES,
+                                               seeds_b + (cur ^ 1) * N, cbits, ids + 16ull * kn);
+                if (lane == 0) { okf[cur ^ 1] = ok; status[kn] = ok ? 0 : HH_ERR_KEY_FORMAT; }
+            }
+        } else if (!okf[cur]) {
+            uint32_t *d = dat + leaf0 * HH_BKT;
+            for (uint64_t q = tid; q < (uint64_t)N * HH_BKT; q += CONSUMERS) d[q] = 0;
+        } else {
+            const bool negate = hdr[L.key_id] != 0;
+            // ---- per-leaf pieces that occupy one lane each, as one work list of 2N items:
+            //  items [0, N): tilde_pi = mmo_hash2to4(seed, x) with x = IntModN::zero() at EVERY leaf (IntModN::one() has
+            //    val 0, common/src/group.rs:448-453, so `x.add(&GIn::one())` never moves), corrected by cs when lsb(seed) = 1;
+            //  items [N, 2N): sign_data and ctr of the converted bucket = the first 8 bytes of counter seed+64.
+            {
+                const uint32_t oc0 = ldb32(hdr + L.oc + 1024), oc1 = ldb32(hdr + L.oc + 1028);
+                uint32_t t0 = 0, t1 = 0;
+#pragma unroll 1
+                for (uint32_t it = tid; it < 2 * N; it += CONSUMERS) {
+                    const uint32_t x = it & (N - 1);
+                    const uint4 s = seeds[x];
+                    const uint32_t m = 0u - (s.x & 1);
+                    B128 c = {{s.x, s.y, s.z, s.w}};
+                    if (it < N) {
+                        const B128 s1 = mmo<NT>(T, rk0, c);
+                        const B128 s3 = mmo<NT>(T, rk0, s1);
+                        const uint8_t *cs = hdr + L.cs;
+                        uint4 *o = tpc + (leaf0 + x) * 4;
+                        B128 q = ldb128(cs);
+                        o[0] = make_uint4(tab->cx[0][0] ^ (q.w[0] & m), tab->cx[0][1] ^ (q.w[1] & m), tab->cx[0][2] ^ (q.w[2] & m), tab->cx[0][3] ^ (q.w[3] & m));
+                        q = ldb128(cs + 16);
+                        o[1] = make_uint4(s1.w[0] ^ (q.w[0] & m), s1.w[1] ^ (q.w[1] & m), s1.w[2] ^ (q.w[2] & m), s1.w[3] ^ (q.w[3] & m));
+                        q = ldb128(cs + 32);
+                        o[2] = make_uint4(tab->cx[0][4] ^ (q.w[0] & m), tab->cx[0][5] ^ (q.w[1] & m), tab->cx[0][6] ^ (q.w[2] & m), tab->cx[0][7] ^ (q.w[3] & m));
+                        q = ldb128(cs + 48);
+                        o[3] = make_uint4(s3.w[0] ^ (q.w[0] & m), s3.w[1] ^ (q.w[1] & m), s3.w[2] ^ (q.w[2] & m), s3.w[3] ^ (q.w[3] & m));
+                    } else {
+                        ctr_add(c, 64);
+                        const B128 o = mmo<NT>(T, rk0, c);
+                        uint32_t a = o.w[0] + (oc0 & m), b = o.w[1] + (oc1 & m);
+                        if (negate) { a = 0u - a; b = 0u - b; }
+                        *reinterpret_cast<uint2 *>(dat + (leaf0 + x) * HH_BKT + 256) = make_uint2(a, b);
+                        t0 += a; t1 += b;
+                    }
+                }
+                if (t0 | t1) { atomicAdd(&red[256], t0); atomicAdd(&red[257], t1); }
+            }
+            // ---- convert::<Bucket<u32>>: 1032 bytes = counters seed+0 .. seed+64 (the last half used, above); one
+            // wavefront per leaf, lane j takes counter j, so a leaf is one 1 KiB coalesced store; the sum over leaves
+            // stays in registers
+            {
+                const B128 oc = ldb128(hdr + L.oc + 16 * lane);
+                uint32_t acc[4] = {0, 0, 0, 0};
+                constexpr uint32_t CW = CONSUMERS / 64;
+                // two leaves per pass: 32 table reads in flight per round instead of 16 keeps the LDS queue fed
+#pragma unroll 1
+#ifdef HH_EXP_NO_CONVERT
+                for (uint32_t x = wv; x < 2 * CW; x += 2 * CW) {
+#else
+                for (uint32_t x = wv; x < N; x += 2 * CW) {
+#endif
+                    const uint32_t x1 = x + CW < N ? x + CW : x;   // the odd leaf out is computed twice, stored once
+                    const uint4 sa = seeds[x], sb = seeds[x1];
+                    B128 ca = {{sa.x, sa.y, sa.z, sa.w}}, cb = {{sb.x, sb.y, sb.z, sb.w}};
+                    ctr_add(ca, lane); ctr_add(cb, lane);
+                    B128 oa, ob;
+                    mmo2<NT>(T, rk0, ca, cb, oa, ob);
+                    const uint32_t ma = 0u - (sa.x & 1), mb = 0u - (sb.x & 1);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        oa.w[q] += oc.w[q] & ma; ob.w[q] += oc.w[q] & mb;
+                        if (negate) { oa.w[q] = 0u - oa.w[q]; ob.w[q] = 0u - ob.w[q]; }
+                        acc[q] += oa.w[q];
+                        if (x1 != x) acc[q] += ob.w[q];
+                    }
+                    uint2 *d = reinterpret_cast<uint2 *>(dat + (leaf0 + x) * HH_BKT + 4 * lane);  // 8-byte aligned only
+                    d[0] = make_uint2(oa.w[0], oa.w[1]);
+                    d[1] = make_uint2(oa.w[2], oa.w[3]);
+                    if (x1 != x) {
+                        d = reinterpret_cast<uint2 *>(dat + (leaf0 + x1) * HH_BKT + 4 * lane);
+                        d[0] = make_uint2(ob.w[0], ob.w[1]);
+                        d[1] = make_uint2(ob.w[2], ob.w[3]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) atomicAdd(&red[4 * lane + q], acc[q]);
+            }
+        }
+        __syncthreads();
+        // this buffer's sums are complete; it is used again two key chains on, a barrier away
+        if (tid < HH_BKT) { buckg[(uint64_t)k * HH_BKT + tid] = red[tid]; red[tid] = 0; }
+    }
 }
 
 // ------------------------------------------------------------------------------------------ support keys
@@ -501,9 +589,10 @@ __global__ __launch_bounds__(64) void k_hh_final(const uint8_t *__restrict__ key
 
 }  // namespace
 
-static int hh_main_tables(uint32_t depth) { return depth <= 10 ? 4 : 2; }
+static int hh_main_tables(uint32_t depth) { return depth <= 9 ? 4 : 2; }
 size_t hh_main_lds_bytes(uint32_t depth) {
-    return 4 * (size_t)T_WORDS * hh_main_tables(depth) + 16 * ((size_t)1 << depth) + HDR_BYTES + 4 * 260 + ((size_t)1 << depth) + 16;
+    const size_t N = (size_t)1 << depth;
+    return 4 * (size_t)T_WORDS * hh_main_tables(depth) + 2 * 16 * N + 2 * HDR_BYTES + 4 * 524 + N + 16;
 }
 
 int launch_hh_eval(const uint8_t *d_keys, uint64_t stride, uint32_t n, uint32_t depth, const HhTables *d_tab,
@@ -514,7 +603,10 @@ int launch_hh_eval(const uint8_t *d_keys, uint64_t stride, uint32_t n, uint32_t 
     auto kmain = hh_main_tables(depth) == 4 ? k_hh_main<4> : k_hh_main<2>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kmain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kmain, dim3(n), dim3(MAIN_THREADS), lds, stream, d_keys, stride, depth, d_tab, d_dat, w.tpc, w.buckg, d_ids, d_status);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint32_t grid = n < (uint32_t)cus ? n : (uint32_t)cus;   // one persistent workgroup per CU
+    hipLaunchKernelGGL(kmain, dim3(grid), dim3(MAIN_THREADS), lds, stream, d_keys, stride, n, depth, d_tab, d_dat, w.tpc, w.buckg, d_ids, d_status);
     const uint64_t sup_threads = (uint64_t)n * HH_SUPPORT;
     hipLaunchKernelGGL(k_hh_support, dim3((uint32_t)((sup_threads + 255) / 256)), dim3(256), 0, stream, d_keys, stride, n, depth, d_tab,
                        w.proofblk, w.supd, d_status);
