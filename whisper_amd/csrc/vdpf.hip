@@ -157,14 +157,16 @@ __device__ __forceinline__ void sha_compress(uint32_t (&h)[8], uint32_t (&w)[16]
         0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
         0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
     uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    // sigma functions as one three-input XOR of rotates, Ch = bitop3 0xca (e ? f : g), Maj = bitop3 0xe8: 15 instructions a
+    // round and 10 per schedule word -- a lone wavefront issues one every ~5 cycles, so the count is the latency
 #pragma unroll
     for (int i = 0; i < 64; i++) {
         if (i >= 16) {
             const uint32_t x = w[(i + 1) & 15], y = w[(i + 14) & 15];
-            w[i & 15] += (rotl(x, 25) ^ rotl(x, 14) ^ (x >> 3)) + (rotl(y, 15) ^ rotl(y, 13) ^ (y >> 10)) + w[(i + 9) & 15];
+            w[i & 15] += xor3(rotl(x, 25), rotl(x, 14), x >> 3) + xor3(rotl(y, 15), rotl(y, 13), y >> 10) + w[(i + 9) & 15];
         }
-        const uint32_t t1 = hh + (rotl(e, 26) ^ rotl(e, 21) ^ rotl(e, 7)) + ((e & f) ^ (~e & g)) + K[i] + w[i & 15];
-        const uint32_t t2 = (rotl(a, 30) ^ rotl(a, 19) ^ rotl(a, 10)) + ((a & b) ^ (a & c) ^ (b & c));
+        const uint32_t t1 = hh + xor3(rotl(e, 26), rotl(e, 21), rotl(e, 7)) + __builtin_amdgcn_bitop3_b32(e, f, g, 0xca) + K[i] + w[i & 15];
+        const uint32_t t2 = xor3(rotl(a, 30), rotl(a, 19), rotl(a, 10)) + __builtin_amdgcn_bitop3_b32(a, b, c, 0xe8);
         hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
     }
     h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
@@ -403,15 +405,16 @@ __global__ __launch_bounds__(1024) void k_hh_main(const uint8_t *__restrict__ ke
 
 // ------------------------------------------------------------------------------------------ support keys
 // VDPFKey<u32>::eval_all::<bool>: one level, two leaves, hashed index x = false, true
-__global__ __launch_bounds__(256) void k_hh_support(const uint8_t *__restrict__ keys, uint64_t stride, uint32_t n, uint32_t depth,
+constexpr uint32_t SUP_THREADS = 1024, TAIL_NT = 4;
+__global__ __launch_bounds__(1024) void k_hh_support(const uint8_t *__restrict__ keys, uint64_t stride, uint32_t n, uint32_t depth,
                                                     const HhTables *__restrict__ tab, uint32_t *__restrict__ proofblk,
                                                     uint32_t *__restrict__ supd, const int32_t *__restrict__ status) {
-    __shared__ uint32_t Tall[T_WORDS];
+    extern __shared__ uint32_t Tall[];   // the four AES tables, 128 KiB
     const uint32_t tid = threadIdx.x;
-    fill_table(Tall, tab, tid, 256);
+    fill_table<TAIL_NT>(Tall, tab, tid, SUP_THREADS);
     __syncthreads();
     const TabRef T = tab_ref(Tall, tid);
-    const uint64_t g = (uint64_t)blockIdx.x * 256 + tid;
+    const uint64_t g = (uint64_t)blockIdx.x * SUP_THREADS + tid;
     if (g >= (uint64_t)n * HH_SUPPORT) return;
     const uint64_t i = g / HH_SUPPORT;
     const uint32_t sup = (uint32_t)(g - i * HH_SUPPORT);
@@ -429,9 +432,9 @@ __global__ __launch_bounds__(256) void k_hh_support(const uint8_t *__restrict__ 
 
     B128 c0 = {{root.w[0] & ~3u, root.w[1], root.w[2], root.w[3]}};
     B128 leaf[2];
-    leaf[0] = mmo(T, rk0, c0);
+    leaf[0] = mmo<TAIL_NT>(T, rk0, c0);
     ctr_add(c0, 1);
-    leaf[1] = mmo(T, rk0, c0);
+    leaf[1] = mmo<TAIL_NT>(T, rk0, c0);
     uint32_t pi[16], d[2];
 #pragma unroll
     for (int k = 0; k < 16; k++) pi[k] = cs[k];
@@ -440,8 +443,8 @@ __global__ __launch_bounds__(256) void k_hh_support(const uint8_t *__restrict__ 
         B128 s = leaf[0];
         if (x) s = leaf[1];
         if (kid) { s.w[0] ^= cw.w[0]; s.w[1] ^= cw.w[1]; s.w[2] ^= cw.w[2]; s.w[3] ^= cw.w[3]; }  // state.bit = key_id at the root
-        const B128 s1 = mmo(T, rk0, s);
-        const B128 s3 = mmo(T, rk0, s1);
+        const B128 s1 = mmo<TAIL_NT>(T, rk0, s);
+        const B128 s3 = mmo<TAIL_NT>(T, rk0, s1);
         const uint32_t m = 0u - (s.w[0] & 1);
         // convert::<u32>: next_u32 -> refill -> the first four bytes of MMO_0(seed), which is s1
         uint32_t word = s1.w[0] + (oc & m);
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(256) void k_hh_support(const uint8_t *__restrict__ 
         }
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            const B128 ho = mmo(T, rk1, hin[b]);
+            const B128 ho = mmo<TAIL_NT>(T, rk1, hin[b]);
 #pragma unroll
             for (int k = 0; k < 4; k++) pi[4 * b + k] ^= ho.w[k];
         }
@@ -474,9 +477,9 @@ __global__ __launch_bounds__(256) void k_hh_support(const uint8_t *__restrict__ 
 __global__ __launch_bounds__(256) void k_hh_chain(const uint8_t *__restrict__ keys, uint64_t stride, uint32_t n, uint32_t depth,
                                                   const HhTables *__restrict__ tab, const uint4 *__restrict__ tpc,
                                                   uint32_t *__restrict__ proofblk, const int32_t *__restrict__ status) {
-    __shared__ uint32_t Tall[T_WORDS];
+    extern __shared__ uint32_t Tall[];   // the four AES tables, 128 KiB
     const uint32_t tid = threadIdx.x;
-    fill_table(Tall, tab, tid, 256);
+    fill_table<TAIL_NT>(Tall, tab, tid, 256);
     __syncthreads();
     const TabRef T = tab_ref(Tall, tid);
     const uint64_t g = (uint64_t)blockIdx.x * 256 + tid;
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(256) void k_hh_chain(const uint8_t *__restrict__ ke
         for (uint32_t x = 0; x < N; x++) {
             const B128 hin = {{pi.w[0] ^ nx.x, pi.w[1] ^ nx.y, pi.w[2] ^ nx.z, pi.w[3] ^ nx.w}};
             if (x + 1 < N) nx = tp[(x + 1) * 4];
-            const B128 ho = mmo(T, rk1, hin);
+            const B128 ho = mmo<TAIL_NT>(T, rk1, hin);
             pi.w[0] ^= ho.w[0]; pi.w[1] ^= ho.w[1]; pi.w[2] ^= ho.w[2]; pi.w[3] ^= ho.w[3];
         }
     }
@@ -510,7 +513,7 @@ __global__ __launch_bounds__(256) void k_hh_chain(const uint8_t *__restrict__ ke
 }
 
 // ------------------------------------------------------------------------------------------ folding and the tag
-// Three SHA-256 messages per key chain, streamed through one compression site:
+// Three SHA-256 messages per key chain:
 //   A  bytes of the folded bucket (258 u32, little endian)                 17 blocks
 //   B  bytes of the support sums (257 u32)                                 17 blocks
 //   C  the proof string: hex(main) | 257 x hex(support) | hex(A) | hex(B)  260 blocks + padding
@@ -532,40 +535,27 @@ __global__ __launch_bounds__(64) void k_hh_final(const uint8_t *__restrict__ key
     uint32_t h[8], hexA[16], hexB[16], w[16];
     sha_init(h);
 #pragma unroll 1
-    for (uint32_t blk = 0; blk < 17 + 17 + 261; blk++) {
-        if (blk < 34) {
-            const bool isA = blk < 17;
-            const uint32_t b = isA ? blk : blk - 17, words = isA ? HH_BKT : HH_SUPPORT;
+    for (uint32_t blk = 0; blk < 34; blk++) {
+        const bool isA = blk < 17;
+        const uint32_t b = isA ? blk : blk - 17, words = isA ? HH_BKT : HH_SUPPORT;
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const uint32_t e = 16 * b + k;
-                uint32_t v = 0;
-                if (e < words) {
-                    const uint32_t d0 = e < HH_SUPPORT ? sd[2 * e] : 0, d1 = e < HH_SUPPORT ? sd[2 * e + 1] : 0;
-                    if (isA) {
-                        // buck -= (right - left) per support key; key 1 also takes 1 off ctr and negates (protocol.rs:99-126)
-                        v = bk[e] - (d1 - d0);
-                        if (kid) { if (e == HH_BKT - 1) v -= 1; v = 0u - v; }
-                    } else {
-                        v = d0 + d1;                      // must be 1 across the two servers (protocol.rs:104-108, 143-148)
-                        if (kid) v = 0u - (v - 1);
-                    }
-                    v = __builtin_bswap32(v);             // little-endian bytes of the u32 as a big-endian message word
-                } else if (e == words) v = 0x80000000u;
-                else if (e == 271) v = words * 32;        // message length in bits
-                w[k] = v;
-            }
-        } else {
-            const uint32_t b = blk - 34;
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                uint32_t v;
-                if (b < HH_SUPPORT + 1) v = pb[16 * b + k];
-                else if (b == HH_SUPPORT + 1) v = hexA[k];
-                else if (b == HH_SUPPORT + 2) v = hexB[k];
-                else v = k == 0 ? 0x80000000u : (k == 15 ? 64u * (HH_SUPPORT + 3) * 8 : 0u);
-                w[k] = v;
-            }
+        for (int k = 0; k < 16; k++) {
+            const uint32_t e = 16 * b + k;
+            uint32_t v = 0;
+            if (e < words) {
+                const uint32_t d0 = e < HH_SUPPORT ? sd[2 * e] : 0, d1 = e < HH_SUPPORT ? sd[2 * e + 1] : 0;
+                if (isA) {
+                    // buck -= (right - left) per support key; key 1 also takes 1 off ctr and negates (protocol.rs:99-126)
+                    v = bk[e] - (d1 - d0);
+                    if (kid) { if (e == HH_BKT - 1) v -= 1; v = 0u - v; }
+                } else {
+                    v = d0 + d1;                      // must be 1 across the two servers (protocol.rs:104-108, 143-148)
+                    if (kid) v = 0u - (v - 1);
+                }
+                v = __builtin_bswap32(v);             // little-endian bytes of the u32 as a big-endian message word
+            } else if (e == words) v = 0x80000000u;
+            else if (e == 271) v = words * 32;        // message length in bits
+            w[k] = v;
         }
         sha_compress(h, w);
         if (blk == 16 || blk == 33) {
@@ -577,6 +567,26 @@ __global__ __launch_bounds__(64) void k_hh_final(const uint8_t *__restrict__ key
             }
             sha_init(h);
         }
+    }
+    // message C: 258 ready-made blocks (four 16-byte loads each, the next block's in flight under the compression),
+    // then hex(A), hex(B) and the padding block
+    const uint4 *pq = reinterpret_cast<const uint4 *>(pb);
+    uint4 nx[4] = {pq[0], pq[1], pq[2], pq[3]};
+#pragma unroll 1
+    for (uint32_t b = 0; b < HH_SUPPORT + 4; b++) {
+        if (b < HH_SUPPORT + 1) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) { w[4 * q] = nx[q].x; w[4 * q + 1] = nx[q].y; w[4 * q + 2] = nx[q].z; w[4 * q + 3] = nx[q].w; }
+            if (b + 1 < HH_SUPPORT + 1) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) nx[q] = pq[4 * (b + 1) + q];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                w[k] = b == HH_SUPPORT + 1 ? hexA[k] : (b == HH_SUPPORT + 2 ? hexB[k] : (k == 0 ? 0x80000000u : (k == 15 ? 64u * (HH_SUPPORT + 3) * 8 : 0u)));
+        }
+        sha_compress(h, w);
     }
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -608,9 +618,12 @@ int launch_hh_eval(const uint8_t *d_keys, uint64_t stride, uint32_t n, uint32_t 
     const uint32_t grid = n < (uint32_t)cus ? n : (uint32_t)cus;   // one persistent workgroup per CU
     hipLaunchKernelGGL(kmain, dim3(grid), dim3(MAIN_THREADS), lds, stream, d_keys, stride, n, depth, d_tab, d_dat, w.tpc, w.buckg, d_ids, d_status);
     const uint64_t sup_threads = (uint64_t)n * HH_SUPPORT;
-    hipLaunchKernelGGL(k_hh_support, dim3((uint32_t)((sup_threads + 255) / 256)), dim3(256), 0, stream, d_keys, stride, n, depth, d_tab,
-                       w.proofblk, w.supd, d_status);
-    hipLaunchKernelGGL(k_hh_chain, dim3((uint32_t)((4ull * n + 255) / 256)), dim3(256), 0, stream, d_keys, stride, n, depth, d_tab, w.tpc, w.proofblk, d_status);
+    const size_t tail_lds = 4 * (size_t)T_WORDS * TAIL_NT;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_hh_support), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail_lds)) != hipSuccess) return (int)e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_hh_chain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail_lds)) != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_hh_support, dim3((uint32_t)((sup_threads + SUP_THREADS - 1) / SUP_THREADS)), dim3(SUP_THREADS), tail_lds, stream, d_keys, stride, n,
+                       depth, d_tab, w.proofblk, w.supd, d_status);
+    hipLaunchKernelGGL(k_hh_chain, dim3((uint32_t)((4ull * n + 255) / 256)), dim3(256), tail_lds, stream, d_keys, stride, n, depth, d_tab, w.tpc, w.proofblk, d_status);
     hipLaunchKernelGGL(k_hh_final, dim3((n + 63) / 64), dim3(64), 0, stream, d_keys, stride, n, depth, w.proofblk, w.supd, w.buckg, d_tags,
                        d_status);
     return (int)hipGetLastError();
