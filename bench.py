@@ -38,6 +38,14 @@ WORKLOADS = {
     "histogram": dict(circuit=W.HISTOGRAM, bits=0, length=128, chunk=64, reports_per_gpu=100_000,
                       desc="Prio3 Histogram length=128 chunk_size=64, 100k clients"),
 }
+# heavy hitters (server-hh): (repetitions, buckets) from the recovery threshold, bin-utils/src/lib.rs:66-88; one step =
+# expansion (eval_and_check) of clients x repetitions key chains + masked sketch sums
+HH_WORKLOADS = {
+    "hh_t0.01": dict(reps=14, buckets=512, clients_per_gpu=1000,
+                     desc="heavy hitters, recovery threshold 0.01: 14 repetitions x 512 buckets, 1000 clients/GPU"),
+    "hh_t0.001": dict(reps=17, buckets=2048, clients_per_gpu=250,
+                      desc="heavy hitters, recovery threshold 0.001: 17 repetitions x 2048 buckets, 250 clients/GPU"),
+}
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 KECCAK_PEAK = 10.6e9         # Keccak-f[1600]/s, measured permutation-only ceiling of this kernel style on MI355X
 
@@ -60,7 +68,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="sumvec_large", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="sumvec_large", choices=sorted(WORKLOADS) + sorted(HH_WORKLOADS))
     ap.add_argument("--reports-per-gpu", type=int, default=0)
     ap.add_argument("--unique", type=int, default=128, help="distinct clients generated on the CPU and tiled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -87,6 +95,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if args.workload in HH_WORKLOADS:
+        return bench_hh(args, rank, local_rank, world, dev, backend)
     wl = WORKLOADS[args.workload]
     n = args.reports_per_gpu or wl["reports_per_gpu"]
     params = W.Prio3Params(wl["circuit"], wl["bits"], wl["length"], wl["chunk"])
@@ -230,6 +240,141 @@ def main():
         dist.destroy_process_group()
     vdaf.close()
     return result
+
+
+def bench_hh(args, rank, local_rank, world, dev, backend):
+    """server-hh's expansion + aggregation (server-hh/src/main.rs:236-283): per repetition, eval_and_check of every client's
+    key chain, then the sum of the kept clients' bucket vectors; across GPUs an integer all-reduce of the sketches."""
+    import torch.distributed as dist
+    from whisper_amd import hh
+    from whisper_amd.dist import all_reduce_sketch_u32
+    wl = HH_WORKLOADS[args.workload]
+    reps, N = wl["reps"], wl["buckets"]
+    clients = args.reports_per_gpu or wl["clients_per_gpu"]
+    depth = N.bit_length() - 1
+    n = clients * reps                                   # key chains per step, repetition-major
+    ln = hh.key_chain_len(depth)
+    rng = np.random.default_rng(0x5748 + rank)
+    K = max(1, min(args.unique, n))
+    t_gen = time.time()
+    uniq = np.zeros((K, ln), np.uint8)
+    for i in range(K):
+        bk = np.where(rng.integers(0, 2, 258) == 1, 1, 0xffffffff).astype(np.uint32)
+        bk[257] = 1
+        uniq[i], _ = hh.gen_key_chain(depth, i, int(rng.integers(0, N)), bk, rng.integers(0, 256, 32, dtype=np.uint8).tobytes())
+    t_gen = time.time() - t_gen
+    keys = uniq[np.arange(n) % K].copy()
+    keys[:, :8] = ((rank << 40) + np.arange(n, dtype=np.uint64) % clients).view(np.uint8).reshape(n, 8)   # client ids
+    h = hh.HeavyHitters(N, device=local_rank)
+    ext = torch.cuda.ExternalStream(h.stream, device=dev)
+    d_keys = torch.from_numpy(keys).to(dev)
+    d_dat = torch.empty((n, N, 258), dtype=torch.int32, device=dev)
+    d_tags = torch.zeros((n, 64), dtype=torch.uint8, device=dev)
+    d_ids = torch.zeros((n, 16), dtype=torch.uint8, device=dev)
+    d_status = torch.zeros(n, dtype=torch.int32, device=dev)
+    keep = np.ones(n, np.uint8)
+    keep[:: 100] = 0                                     # 1 % of the clients flagged by the group test
+    d_keep = torch.from_numpy(keep).to(dev)
+    d_acc = torch.zeros((reps, N, 258), dtype=torch.int32, device=dev)
+    words = N * 258
+    torch.cuda.synchronize()
+
+    def step():
+        h.eval_and_check_dev(VK, d_keys.data_ptr(), ln, n, d_dat.data_ptr(), d_tags.data_ptr(), d_ids.data_ptr(), d_status.data_ptr())
+        for r in range(reps):                            # one sketch per repetition (aggregate_hhs)
+            h.bucket_sum_u32_dev(d_dat.data_ptr() + 4 * r * clients * words, d_keep.data_ptr() + r * clients, clients, words,
+                                 d_acc.data_ptr() + 4 * r * words)
+        if world > 1:
+            with torch.cuda.stream(ext):
+                all_reduce_sketch_u32(d_acc)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        h.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    h.set_profiling(True)
+    h.kernel_times(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ktimes = h.kernel_times(reset=True)
+    h.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    n_bad_status = int((d_status != 0).sum().item())
+    result = None
+    if rank == 0:
+        kernels = {k: {"ms_per_step": ms / args.steps, "launches_per_step": cnt / args.steps} for k, (ms, cnt) in ktimes.items() if cnt}
+        main_ms = kernels["hh_main"]["ms_per_step"] / kernels["hh_main"]["launches_per_step"]
+        # k_hh_main per key chain: the key chain read, the bucket vectors and the corrected leaf hashes written
+        main_bytes = n * (ln + 4 * words + 64 * N + 4 * 258 + 20)
+        # AES blocks the algorithm needs per key chain (DESIGN.md): tree, leaf hashes, 65 counters per leaf, proof chain,
+        # 14 per support key, testing id; in k_hh_main: all but the chain and the support keys
+        aes_all = 2 * (N - 1) + 2 * N + 65 * N + 4 * N + 257 * 14 + 1
+        aes_main = 2 * (N - 1) + 2 * N + 65 * N + 1
+        issue_cycles = 160 * (4.2 + 2.6) + 16 * 2.6 + 80 * 2.3    # per block and wavefront on one of 4 SIMDs (tools/aes_microbench.hip)
+        aes_peak = 256 * 2.4e9 * 4 * 64 / issue_cycles
+        value = world * n * args.steps / elapsed
+        result = {
+            "metric": "expanded+aggregated heavy-hitter key chains/sec (node), eval_and_check + sketch sums",
+            "value": value, "unit": "key chains/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8 (AES-128 state bytes) + u32 (counters mod 2^32)", "data": "synthetic",
+            "config": {"workload": wl["desc"], "clients_per_gpu": clients, "repetitions": reps, "buckets": N,
+                       "key_chains_per_step_per_gpu": n, "key_chain_bytes": ln, "distinct_key_chains_tiled": K,
+                       "inputs": "resident in HBM", "status_nonzero": n_bad_status, "client_gen_s": round(t_gen, 2),
+                       "parallelism": f"key chains sharded over {world} GPU(s); integer all-reduce of the sketches"},
+            "roofline": {"bound": "hbm", "kernel": "k_hh_main", "achieved": main_bytes / (main_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": main_bytes / (main_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": main_ms, "alg_bytes_per_launch": main_bytes,
+                         "note": "table-driven AES is bound by instruction issue, not by HBM; see valu"},
+            "valu": {"aes_blocks_per_step": n * aes_all, "aes_blocks_per_s": n * aes_all * args.steps / elapsed * world,
+                     "k_hh_main_aes_blocks_per_s": n * aes_main / (main_ms * 1e-3), "aes_issue_bound_blocks_per_s": aes_peak,
+                     "frac": n * aes_main / (main_ms * 1e-3) / aes_peak,
+                     "note": "bound = 160 x (v_perm_b32 4.2 + ds_read_b32 2.6) + 16 x 2.6 + 80 x 2.3 issue cycles per block and "
+                             "wavefront; VALU and LDS instructions of a wavefront's SIMD do not overlap "
+                             "(tools/aes_microbench.hip, profiles/r1_aes_microbench.txt); frac is k_hh_main's"},
+            "kernels": kernels,
+        }
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline_hh(depth, keys, reps, clients, max(1, min(16, os.cpu_count() or 1)), args.cpu_seconds)
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    h.close()
+    return result
+
+
+def cpu_baseline_hh(depth, keys, reps, clients, nthreads, budget_s):
+    """The oracle's eval_and_check (AES-NI when the host has it) + bucket sums on the host cores over a bounded sample
+    of the same key chains.  The only place the heavy-hitter bench touches oracle/."""
+    import oracle_lib as O
+    m = min(len(keys), nthreads * 64)
+    done, spent = 0, 0.0
+    while True:
+        t0 = time.perf_counter()
+        dat, _, _, status = O.hh_eval_and_check_batch(depth, VK, keys[:m], nthreads=nthreads)
+        O.hh_bucket_sum_u32(dat)
+        dt = time.perf_counter() - t0
+        assert not status.any()
+        done, spent = m, dt
+        want = min(len(keys), int(m * min(8.0, budget_s / max(dt, 1e-3))))
+        if dt >= budget_s / 2 or want <= m:
+            break
+        m = want
+    return {"value": done / spent, "unit": "key chains/s", "cores": nthreads, "kind": "port",
+            "sample": f"{done} key chains of the same workload in {spent:.2f} s, {nthreads} threads, "
+                      f"{'AES-NI' if O.aes_backend() else 'portable AES'}; oracle/vdpf.c = C restatement of eval_and_check"}
 
 
 def cpu_baseline(wl, reports, nthreads, budget_s):

@@ -200,7 +200,8 @@ int32_t wh_ctx_synchronize(wh_ctx *ctx);
  * 276,340-341,414-421).  With profiling on, every kernel launch is bracketed by HIP events on
  * the context stream; wh_ctx_kernel_times synchronises and returns accumulated milliseconds and
  * launch counts per kernel (indices WH_K_*), optionally resetting them. */
-enum { WH_K_PARSE = 0, WH_K_EXPAND = 1, WH_K_HASH = 2, WH_K_QUERY = 3, WH_K_AGG = 4, WH_K_HH = 5, WH_K_MEAS = 6, WH_K_HH_EVAL = 7, WH_NUM_KERNELS = 8 };
+enum { WH_K_PARSE = 0, WH_K_EXPAND = 1, WH_K_HASH = 2, WH_K_QUERY = 3, WH_K_AGG = 4, WH_K_HH = 5, WH_K_MEAS = 6,
+       WH_K_HH_MAIN = 7, WH_K_HH_SUPPORT = 8, WH_K_HH_CHAIN = 9, WH_K_HH_FINAL = 10, WH_NUM_KERNELS = 11 };
 int32_t wh_ctx_set_profiling(wh_ctx *ctx, int32_t on);
 int32_t wh_ctx_kernel_times(wh_ctx *ctx, double *ms, uint64_t *launches, int32_t reset);
 

@@ -86,3 +86,57 @@ def test_two_rank_allgather_reduce_matches_single_process():
     for r in range(world):
         keep[shard_bounds(n, world, r)[0]] = 0
     assert total == O.prio3_aggregate(outs, p.output_len, keep).tobytes()
+
+
+def _hh_worker(rank, world, port, n, depth, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib as O
+    from whisper_amd.dist import shard_bounds, all_reduce_sketch_u32
+    keys = _hh_keys(n, depth)
+    lo, hi = shard_bounds(n, world, rank)
+    dat, _, _, status = O.hh_eval_and_check_batch(depth, bytes(16), keys[lo:hi], nthreads=1)
+    assert not status.any()
+    keep = np.ones(hi - lo, np.uint8)
+    keep[0] = 0
+    acc = torch.from_numpy(O.hh_bucket_sum_u32(dat, keep).astype(np.uint32).view(np.int32).copy())
+    all_reduce_sketch_u32(acc)
+    if rank == 0:
+        q.put(acc.numpy().view(np.uint32).tobytes())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _hh_keys(n, depth):
+    import oracle_lib as O
+    rng = np.random.default_rng(31)
+    keys = np.zeros((n, O.hh_key_chain_len(depth)), np.uint8)
+    for i in range(n):
+        bk = np.where(rng.integers(0, 2, 258) == 1, 1, 0xffffffff).astype(np.uint32)
+        bk[257] = 1
+        a, _ = O.hh_gen_key_chain(depth, i, int(rng.integers(0, 1 << depth)), bk, rng.integers(0, 256, 32, dtype=np.uint8).tobytes())
+        keys[i] = np.frombuffer(a, np.uint8)
+    return keys
+
+
+def test_two_rank_sketch_allreduce_matches_single_process():
+    """Heavy hitters over two ranks: key chains sharded by index, per-rank sketch sums, integer all-reduce."""
+    import oracle_lib as O
+    from whisper_amd.dist import shard_bounds
+    n, world, depth = 9, 2, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hh_worker, args=(r, world, port, n, depth, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    total = q.get(timeout=120)
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    dat, _, _, _ = O.hh_eval_and_check_batch(depth, bytes(16), _hh_keys(n, depth), nthreads=1)
+    keep = np.ones(n, np.uint8)
+    for r in range(world):
+        keep[shard_bounds(n, world, r)[0]] = 0
+    assert total == O.hh_bucket_sum_u32(dat, keep).astype(np.uint32).tobytes()

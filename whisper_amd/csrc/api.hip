@@ -699,9 +699,13 @@ int32_t wh_hh_eval_and_check_batch_dev(wh_ctx *c, const uint8_t verify_key[16], 
     c->d_hh_dat_last = d_dat; c->hh_n_last = n; c->hh_depth_last = depth;
     for (uint64_t base = 0; base < n; base += cap) {
         const uint32_t m = (uint32_t)(n - base < cap ? n - base : cap);
-        KTimer t_(c, WH_K_HH_EVAL);
-        const int e = launch_hh_eval(d_keys + base * stride, stride, m, depth, c->d_hh_tab, c->hh_w, d_dat + base * words,
-                                     d_tags + 64 * base, d_ids + 16 * base, d_status + base, c->stream);
+        const uint8_t *kp = d_keys + base * stride;
+        int e;
+        { KTimer t_(c, WH_K_HH_MAIN);
+          e = launch_hh_main(kp, stride, m, depth, c->d_hh_tab, c->hh_w, d_dat + base * words, d_ids + 16 * base, d_status + base, c->stream); }
+        if (!e) { KTimer t_(c, WH_K_HH_SUPPORT); e = launch_hh_support(kp, stride, m, depth, c->d_hh_tab, c->hh_w, d_status + base, c->stream); }
+        if (!e) { KTimer t_(c, WH_K_HH_CHAIN); e = launch_hh_chain(kp, stride, m, depth, c->d_hh_tab, c->hh_w, d_status + base, c->stream); }
+        if (!e) { KTimer t_(c, WH_K_HH_FINAL); e = launch_hh_final(kp, stride, m, depth, c->hh_w, d_tags + 64 * base, d_status + base, c->stream); }
         if (e) { c->err = std::string("heavy-hitter eval launch: ") + hipGetErrorString((hipError_t)e); return WH_ERR_HIP; }
     }
     return WH_OK;

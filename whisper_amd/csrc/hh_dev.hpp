@@ -36,9 +36,15 @@ struct HhWork {
     uint32_t *buckg;     // [cap][258]     sum of the main key's outputs over all leaves
 };
 
-int launch_hh_eval(const uint8_t *d_keys, uint64_t stride, uint32_t n, uint32_t depth, const HhTables *d_tab,
-                   const HhWork &w, uint32_t *d_dat, uint8_t *d_tags, uint8_t *d_ids, int32_t *d_status,
-                   hipStream_t stream);
+// the four launches of one sub-batch, in this order on one stream; each returns a hipError_t as int
+int launch_hh_main(const uint8_t *d_keys, uint64_t stride, uint32_t n, uint32_t depth, const HhTables *d_tab, const HhWork &w,
+                   uint32_t *d_dat, uint8_t *d_ids, int32_t *d_status, hipStream_t stream);
+int launch_hh_support(const uint8_t *d_keys, uint64_t stride, uint32_t n, uint32_t depth, const HhTables *d_tab, const HhWork &w,
+                      const int32_t *d_status, hipStream_t stream);
+int launch_hh_chain(const uint8_t *d_keys, uint64_t stride, uint32_t n, uint32_t depth, const HhTables *d_tab, const HhWork &w,
+                    const int32_t *d_status, hipStream_t stream);
+int launch_hh_final(const uint8_t *d_keys, uint64_t stride, uint32_t n, uint32_t depth, const HhWork &w, uint8_t *d_tags,
+                    const int32_t *d_status, hipStream_t stream);
 size_t hh_main_lds_bytes(uint32_t depth);
 
 }  // namespace wh

@@ -605,10 +605,8 @@ size_t hh_main_lds_bytes(uint32_t depth) {
     return 4 * (size_t)T_WORDS * hh_main_tables(depth) + 2 * 16 * N + 2 * HDR_BYTES + 4 * 524 + N + 16;
 }
 
-int launch_hh_eval(const uint8_t *d_keys, uint64_t stride, uint32_t n, uint32_t depth, const HhTables *d_tab,
-                   const HhWork &w, uint32_t *d_dat, uint8_t *d_tags, uint8_t *d_ids, int32_t *d_status,
-                   hipStream_t stream) {
-    if (!n) return 0;
+int launch_hh_main(const uint8_t *d_keys, uint64_t stride, uint32_t n, uint32_t depth, const HhTables *d_tab, const HhWork &w,
+                   uint32_t *d_dat, uint8_t *d_ids, int32_t *d_status, hipStream_t stream) {
     const size_t lds = hh_main_lds_bytes(depth);
     auto kmain = hh_main_tables(depth) == 4 ? k_hh_main<4> : k_hh_main<2>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kmain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -617,13 +615,27 @@ int launch_hh_eval(const uint8_t *d_keys, uint64_t stride, uint32_t n, uint32_t 
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const uint32_t grid = n < (uint32_t)cus ? n : (uint32_t)cus;   // one persistent workgroup per CU
     hipLaunchKernelGGL(kmain, dim3(grid), dim3(MAIN_THREADS), lds, stream, d_keys, stride, n, depth, d_tab, d_dat, w.tpc, w.buckg, d_ids, d_status);
+    return (int)hipGetLastError();
+}
+static const size_t TAIL_LDS = 4 * (size_t)T_WORDS * TAIL_NT;
+int launch_hh_support(const uint8_t *d_keys, uint64_t stride, uint32_t n, uint32_t depth, const HhTables *d_tab, const HhWork &w,
+                      const int32_t *d_status, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_hh_support), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TAIL_LDS);
+    if (e != hipSuccess) return (int)e;
     const uint64_t sup_threads = (uint64_t)n * HH_SUPPORT;
-    const size_t tail_lds = 4 * (size_t)T_WORDS * TAIL_NT;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_hh_support), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail_lds)) != hipSuccess) return (int)e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_hh_chain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail_lds)) != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k_hh_support, dim3((uint32_t)((sup_threads + SUP_THREADS - 1) / SUP_THREADS)), dim3(SUP_THREADS), tail_lds, stream, d_keys, stride, n,
+    hipLaunchKernelGGL(k_hh_support, dim3((uint32_t)((sup_threads + SUP_THREADS - 1) / SUP_THREADS)), dim3(SUP_THREADS), TAIL_LDS, stream, d_keys, stride, n,
                        depth, d_tab, w.proofblk, w.supd, d_status);
-    hipLaunchKernelGGL(k_hh_chain, dim3((uint32_t)((4ull * n + 255) / 256)), dim3(256), tail_lds, stream, d_keys, stride, n, depth, d_tab, w.tpc, w.proofblk, d_status);
+    return (int)hipGetLastError();
+}
+int launch_hh_chain(const uint8_t *d_keys, uint64_t stride, uint32_t n, uint32_t depth, const HhTables *d_tab, const HhWork &w,
+                    const int32_t *d_status, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_hh_chain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TAIL_LDS);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_hh_chain, dim3((uint32_t)((4ull * n + 255) / 256)), dim3(256), TAIL_LDS, stream, d_keys, stride, n, depth, d_tab, w.tpc, w.proofblk, d_status);
+    return (int)hipGetLastError();
+}
+int launch_hh_final(const uint8_t *d_keys, uint64_t stride, uint32_t n, uint32_t depth, const HhWork &w, uint8_t *d_tags,
+                    const int32_t *d_status, hipStream_t stream) {
     hipLaunchKernelGGL(k_hh_final, dim3((n + 63) / 64), dim3(64), 0, stream, d_keys, stride, n, depth, w.proofblk, w.supd, w.buckg, d_tags,
                        d_status);
     return (int)hipGetLastError();

@@ -37,3 +37,21 @@ def merge_partials(partial, sum_rows, group=None):
     """all-gather + reduction; `sum_rows(rows[world, L]) -> [L]` is the mod-p row sum
     (Prio3.sum_rows_dev on the GPU)."""
     return sum_rows(all_gather_partials(partial, group))
+
+
+def all_reduce_sketch_u32(acc, group=None):
+    """Heavy-hitter sketches: counters live in Z/2^32 (AggRing = u32, hhcore/src/lib.rs:13), so the per-GPU partial
+    sums combine with a plain integer all-reduce (ncclSum on int32 wraps exactly like u32::wrapping_add,
+    common/src/group.rs:88-91) -- the counterpart of CountSketch::insert over partial sketches (countsketch.rs:22-28).
+    acc: int32/uint32 tensor; reduced in place and returned."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return acc
+    view = acc.view(torch.int32)
+    if view.is_cuda and dist.get_backend(group) == "gloo":
+        host = view.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        view.copy_(host.to(view.device))
+        return acc
+    dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)
+    return acc

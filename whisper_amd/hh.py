@@ -10,6 +10,7 @@ import ctypes as C
 import numpy as np
 
 from ._lib import lib, WhError
+from .prio3 import KERNELS
 
 BUCKET_WORDS = 258  # STRING_SIZE + 2
 MAX_DEPTH = 11      # num_buckets <= 2048 (server-hh/src/main.rs:428-436)
@@ -112,3 +113,18 @@ class HeavyHitters:
 
     def aggregate_hhs_dev(self, d_keep, d_acc, accumulate=False):
         self._chk(lib.wh_hh_aggregate_dev(self._ctx, d_keep, d_acc, 1 if accumulate else 0), "hh_aggregate_dev")
+
+    def bucket_sum_u32_dev(self, d_buckets, d_keep, n, words, d_acc, accumulate=False):
+        """aggregate_hhs over caller-owned device buffers: buckets[n][words] u32 -> acc[words]."""
+        fn = lib.wh_hh_bucket_accumulate_u32_dev if accumulate else lib.wh_hh_bucket_sum_u32_dev
+        self._chk(fn(self._ctx, d_buckets, d_keep, n, words, d_acc), "hh_bucket_sum")
+
+    def set_profiling(self, on=True):
+        self._chk(lib.wh_ctx_set_profiling(self._ctx, int(on)), "set_profiling")
+
+    def kernel_times(self, reset=True):
+        """{kernel: (milliseconds, launches)} accumulated by HIP events on the context stream since the last reset."""
+        ms = np.zeros(len(KERNELS), np.float64)
+        cnt = np.zeros(len(KERNELS), np.uint64)
+        self._chk(lib.wh_ctx_kernel_times(self._ctx, ms.ctypes.data, cnt.ctypes.data, int(reset)), "kernel_times")
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(KERNELS)}

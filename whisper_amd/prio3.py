@@ -81,6 +81,10 @@ def shard_batched_many(params, measurements, nonces, rands, first_client_id=0, n
     return lr, hr
 
 
+# indices WH_K_* of wh_ctx_kernel_times
+KERNELS = ("parse", "expand", "hash", "query", "aggregate", "hh_sum", "meas", "hh_main", "hh_support", "hh_chain", "hh_final")
+
+
 class Prio3:
     """One Prio3 instance bound to one GPU (one wh_ctx)."""
 
@@ -234,7 +238,7 @@ class Prio3:
         self._chk(fn(self._ctx, d_buckets, d_keep, n, words, d_acc), "hh_bucket_sum")
 
     # ---- measurement ----
-    KERNELS = ("parse", "expand", "hash", "query", "aggregate", "hh_sum", "meas", "hh_eval")
+    KERNELS = KERNELS
 
     def set_profiling(self, on=True):
         self._chk(lib.wh_ctx_set_profiling(self._ctx, int(on)), "set_profiling")
