@@ -146,3 +146,37 @@ def test_sub_batches_and_device_entry():
     want = o.hh_bucket_sum_u32(odat)
     assert (d_acc.cpu().numpy().view(np.uint32) == (want + want)).all()
     h.close()
+
+
+def test_server_hh_flow_with_group_test():
+    """batch_collect_and_aggregate_per_run + aggregate_hhs (server-hh/src/main.rs:53-110, 255-282) for Alice and Bob:
+    expansion on the GPU, sort by testing id, general_binary_split_test over the String tags with the 32-byte (SHA-256)
+    batch proofs the heavy-hitter server asks for (main.rs:61-68), masked sketch sums, and the two servers' sketches
+    inserted into each other (main.rs:386-391) give the honest clients' buckets."""
+    from whisper_amd import hh
+    from whisper_amd.grouptest import ClientProofTag, general_binary_split_test
+    depth, n, bad = 5, 60, {0, 13, 14, 41, 59}
+    vk = bytes(range(100, 116))
+    A, B, alphas, bks = _make(depth, n, 2024, bad)
+    servers = []
+    for keys in (A, B):
+        h = hh.HeavyHitters(1 << depth)
+        tags, ids, status = h.eval_and_check(vk, keys)
+        assert not status.any()
+        order = sorted(range(n), key=lambda i: ids[i])                       # par_sort_by testing_id
+        proofs = [ClientProofTag(ids[i], tags[i].encode()) for i in order]
+        servers.append((h, ids, proofs))
+    bad_a, bad_b, rounds = general_binary_split_test(servers[0][2], servers[1][2], vk, len(bad), tag_size=32)
+    ids = servers[0][1]
+    assert servers[1][1] == ids                                              # same PRF key, same client ids
+    assert bad_a == bad_b == {ids[i] for i in bad} and rounds > 1
+    sketches = []
+    for (h, ids_, _), bad_ids in zip(servers, (bad_a, bad_b)):
+        keep = np.array([ids_[i] not in bad_ids for i in range(n)], np.uint8)
+        sketches.append(h.aggregate_hhs(keep))
+        h.close()
+    want = np.zeros((1 << depth, 258), np.uint32)
+    for i in range(n):
+        if i not in bad:
+            want[alphas[i]] += bks[i]
+    assert ((sketches[0] + sketches[1]) == want).all()
