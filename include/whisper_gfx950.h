@@ -135,6 +135,13 @@ int32_t wh_flp_query_batch(wh_ctx *ctx, const uint8_t *input, const uint8_t *pro
                            const uint8_t *joint_rand, uint32_t num_shares, uint64_t n, uint8_t *verifier, int32_t *status);
 /* replaces: Type::decide (flp.rs:483-512) for n verifiers: decision[i] = 1 accept, 0 reject, WH_ERR_MODULUS. */
 int32_t wh_flp_decide_batch(wh_ctx *ctx, const uint8_t *verifier, uint64_t n, int32_t *decision);
+/* replaces: Type::prove (flp.rs:231-347) with num_shares = 1 for n independent tuples on the GPU (the client-side half of
+ * the proof system; the meta-client of the reference proves on the CPU, client-batch-prio3/src/main.rs:67-153).  HOST
+ * buffers of n rows: input[input_len], prove_rand[arity], joint_rand[joint_rand_len] elements; proof: n * proof_len
+ * elements.  status per tuple: WH_ERR_MODULUS for a non-canonical element (the proof row is then zero).  Circuits with more
+ * than 511 gadget calls: WH_ERR_UNSUPPORTED. */
+int32_t wh_flp_prove_batch(wh_ctx *ctx, const uint8_t *input, const uint8_t *prove_rand, const uint8_t *joint_rand, uint64_t n,
+                           uint8_t *proof, int32_t *status);
 /* replaces (CPU, client side): Type::encode_measurement (types.rs:582-606, 388-399, 246-253) and Type::prove
  * (flp.rs:231-347) with num_shares = 1; prove_rand: arity elements, joint_rand: joint_rand_len elements. */
 int32_t wh_flp_encode(const wh_prio3_params *params, const uint64_t *measurement, uint8_t *input);
@@ -201,7 +208,7 @@ int32_t wh_ctx_synchronize(wh_ctx *ctx);
  * the context stream; wh_ctx_kernel_times synchronises and returns accumulated milliseconds and
  * launch counts per kernel (indices WH_K_*), optionally resetting them. */
 enum { WH_K_PARSE = 0, WH_K_EXPAND = 1, WH_K_HASH = 2, WH_K_QUERY = 3, WH_K_AGG = 4, WH_K_HH = 5, WH_K_MEAS = 6,
-       WH_K_HH_MAIN = 7, WH_K_HH_SUPPORT = 8, WH_K_HH_CHAIN = 9, WH_K_HH_FINAL = 10, WH_NUM_KERNELS = 11 };
+       WH_K_HH_MAIN = 7, WH_K_HH_SUPPORT = 8, WH_K_HH_CHAIN = 9, WH_K_HH_FINAL = 10, WH_K_PROVE = 11, WH_NUM_KERNELS = 12 };
 int32_t wh_ctx_set_profiling(wh_ctx *ctx, int32_t on);
 int32_t wh_ctx_kernel_times(wh_ctx *ctx, double *ms, uint64_t *launches, int32_t reset);
 

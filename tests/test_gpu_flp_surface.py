@@ -89,3 +89,54 @@ def test_prove_query_decide_match_oracle(name, cfg):
         assert total == ver[0].tobytes()
     finally:
         vdaf.close()
+
+
+PROVE_CASES = CASES + [
+    ("sumvec_large", (W.SUMVEC, 16, 1024, 128)),     # m = 256, 256 wires: BASELINE.json's headline shape
+    ("sumvec_m512", (W.SUMVEC, 4, 700, 8)),          # 350 calls -> m = 512, the largest the kernel's LDS takes
+    ("sumvec_tiny", (W.SUMVEC, 2, 5, 3)),            # m = 8: fewer points than lanes
+    ("histogram_2_1", (W.HISTOGRAM, 0, 2, 1)),       # one wire pair
+]
+
+
+@pytest.mark.parametrize("name,cfg", PROVE_CASES, ids=[c[0] for c in PROVE_CASES])
+def test_gpu_prove_matches_oracle(name, cfg):
+    """Type::prove on the GPU (wh_flp_prove_batch) against the oracle's prove (pinned by the draft-07 shard vectors) and
+    the CPU client's, bit for bit: valid encodings, arbitrary field elements as input (prove does not need a valid
+    measurement), and a non-canonical element."""
+    circ, bits, ln, ch = cfg
+    p = W.Prio3Params(circ, bits, ln, ch)
+    op = O.params(circ, bits, ln, ch)
+    s = p.sizes
+    vdaf = W.Prio3(p)
+    try:
+        n = 5
+        inputs, prs, jrs = [], [], []
+        for i in range(n):
+            if i < 2:
+                if circ == W.SUMVEC:
+                    meas = [int(x) & ((1 << bits) - 1) for x in np.frombuffer(det(b"gp%d" % i, 8 * ln), np.uint64)]
+                elif circ == W.HISTOGRAM:
+                    meas = [(3 * i + 1) % ln]
+                else:
+                    meas = [int.from_bytes(bytes(det(b"gp%d" % i, 8)), "little") & 0xffffffff]
+                inp = W.flp_encode(p, meas).tobytes()
+            else:
+                inp = rand_elems(b"gx%d" % i, s.input_len)
+            inputs.append(inp); prs.append(rand_elems(b"gr%d" % i, s.arity)); jrs.append(rand_elems(b"gj%d" % i, s.joint_rand_len))
+        inputs[4] = inputs[4][:16 * (s.input_len - 1)] + (O.P128 + 1).to_bytes(16, "little")     # not a canonical residue
+        arr = lambda rows: np.frombuffer(b"".join(rows), np.uint8).reshape(len(rows), -1)
+        proofs, status = vdaf.flp_prove(arr(inputs), arr(prs), arr(jrs))
+        assert [int(x) for x in status] == [0, 0, 0, 0, -3]
+        assert not proofs[4].any()
+        for i in range(4):
+            want = O.flp_prove(op, inputs[i], prs[i], jrs[i])
+            assert proofs[i].tobytes() == want, i
+        cpu = W.flp_prove(p, np.frombuffer(inputs[0], np.uint8), np.frombuffer(prs[0], np.uint8), np.frombuffer(jrs[0], np.uint8))
+        assert proofs[0].tobytes() == cpu.tobytes()
+        # and the proof of a valid input verifies on the GPU
+        qr = rand_elems(b"gq", 1)
+        ver, st = vdaf.flp_query(arr(inputs[:2]), proofs[:2], arr([qr, qr]), arr(jrs[:2]), 1)
+        assert not st.any() and all(vdaf.flp_decide(ver))
+    finally:
+        vdaf.close()

@@ -9,6 +9,7 @@
 #include "host_math.hpp"
 #include "aes_host.hpp"
 #include "hh_dev.hpp"
+#include "prove_dev.hpp"
 #include "kernels.hip"
 
 using namespace wh;
@@ -51,6 +52,8 @@ struct wh_ctx {
     struct Ev { hipEvent_t a, b; int id; };
     std::vector<Ev> evs;
     std::vector<hipEvent_t> ev_pool;
+    // prover (prove.hip): transform tables, built on first use
+    F128 *d_omega2m = nullptr, *d_twist = nullptr;
     // heavy-hitter key chains (vdpf.hip)
     HhTables *d_hh_tab = nullptr; bool hh_tab_valid = false; uint8_t hh_vk[16] = {0};
     HhWork hh_w{}; uint64_t hh_cap = 0; uint32_t hh_cap_depth = 0;
@@ -265,7 +268,7 @@ void wh_ctx_destroy(wh_ctx *c) {
     void *ptrs[] = {c->d_omega, c->d_stab, c->d_aes, c->d_out_shares, c->d_status_own, c->d_keep_eff, c->d_partials,
                     c->d_blob, c->d_offsets, c->d_tags, c->d_ids, c->d_prep, c->W.desc, c->W.scal, c->W.weights, c->W.wlimbs, c->W.pows, c->W.rlc,
                     c->W.hrows, c->W.hlist, c->W.llist, c->W.dirty, c->W.counters,
-                    c->d_hh_tab, c->hh_w.tpc, c->hh_w.proofblk, c->hh_w.supd, c->hh_w.buckg, c->d_hh_dat, c->d_hh_keys, c->d_hh_tags,
+                    c->d_omega2m, c->d_twist, c->d_hh_tab, c->hh_w.tpc, c->hh_w.proofblk, c->hh_w.supd, c->hh_w.buckg, c->d_hh_dat, c->d_hh_keys, c->d_hh_tags,
                     c->d_hh_ids, c->d_hh_status, c->d_hh_keep, c->d_hh_acc};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -480,6 +483,52 @@ int32_t wh_flp_query_batch(wh_ctx *c, const uint8_t *input, const uint8_t *proof
                        reinterpret_cast<uint8_t *>(c->d_out_shares), c->d_status_own);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(verifier, c->d_prep, ver_b, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(status, c->d_status_own, 4 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return WH_OK;
+}
+
+int32_t wh_flp_prove_batch(wh_ctx *c, const uint8_t *input, const uint8_t *prove_rand, const uint8_t *joint_rand, uint64_t n,
+                           uint8_t *proof, int32_t *status) {
+    if (!c || (n && (!input || !prove_rand || !proof || !status)) || (n && c->z.jr_len && !joint_rand)) return WH_ERR_PARAM;
+    if (n > 0x7fffffffull) return WH_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    const HostSizes &z = c->z;
+    if (z.m > PROVE_MAX_M) { c->err = "flp prove: more than 511 gadget calls do not fit the kernel's LDS"; return WH_ERR_UNSUPPORTED; }
+    if (!n) return WH_OK;
+    int32_t rc;
+    if (!c->d_omega2m) {
+        // w_2m^k, and the twist w_2m^bitrev(pos) / m that turns coefficients into the odd half of the 2m evaluations
+        const uint32_t m = z.m, two_m = 2 * z.m;
+        std::vector<F128> om(two_m), tw(m);
+        const F128 w = root_of_unity(z.log2m + 1), minv = f_inv(f_small(m));
+        om[0] = f_one();
+        for (uint32_t k = 1; k < two_m; k++) om[k] = f_mul(om[k - 1], w);
+        for (uint32_t pos = 0; pos < m; pos++) {
+            uint32_t r = 0;
+            for (uint32_t b = 0; b < z.log2m; b++) r |= ((pos >> b) & 1) << (z.log2m - 1 - b);
+            tw[pos] = f_mul(om[r], minv);
+        }
+        HIPCHK(c, hipMalloc((void **)&c->d_omega2m, two_m * sizeof(F128)));
+        HIPCHK(c, hipMalloc((void **)&c->d_twist, m * sizeof(F128)));
+        HIPCHK(c, hipMemcpy(c->d_omega2m, om.data(), two_m * sizeof(F128), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_twist, tw.data(), m * sizeof(F128), hipMemcpyHostToDevice));
+    }
+    ProveDev D{z.input_len, c->params.chunk, z.calls, z.m, z.log2m, z.arity, z.gpoly_len, z.proof_len, z.jr_len,
+               c->d_omega2m, c->d_twist, f_inv(f_small(2ull * z.m))};
+    const uint64_t in_b = 16ull * z.input_len * n, pr_b = 16ull * z.arity * n, jr_b = 16ull * z.jr_len * n, pf_b = 16ull * z.proof_len * n;
+    if ((rc = ensure(c, c->d_blob, c->blob_cap, in_b + pr_b + jr_b + 64))) return rc;
+    if ((rc = ensure(c, c->d_prep, c->prep_cap, pf_b))) return rc;
+    if ((rc = ensure(c, c->d_status_own, c->status_cap, n))) return rc;
+    uint8_t *d_in = c->d_blob, *d_pr = d_in + in_b, *d_jr = d_pr + pr_b;
+    HIPCHK(c, hipMemcpyAsync(d_in, input, in_b, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_pr, prove_rand, pr_b, hipMemcpyHostToDevice, c->stream));
+    if (jr_b) HIPCHK(c, hipMemcpyAsync(d_jr, joint_rand, jr_b, hipMemcpyHostToDevice, c->stream));
+    int e;
+    { KTimer t_(c, WH_K_PROVE);
+      e = launch_flp_prove(D, c->params.circuit != WH_AVERAGE, d_in, d_pr, d_jr, (uint32_t)n, c->d_prep, c->d_status_own, c->stream); }
+    if (e) { c->err = std::string("flp prove launch: ") + hipGetErrorString((hipError_t)e); return WH_ERR_HIP; }
+    HIPCHK(c, hipMemcpyAsync(proof, c->d_prep, pf_b, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(status, c->d_status_own, 4 * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return WH_OK;

@@ -82,7 +82,7 @@ def shard_batched_many(params, measurements, nonces, rands, first_client_id=0, n
 
 
 # indices WH_K_* of wh_ctx_kernel_times
-KERNELS = ("parse", "expand", "hash", "query", "aggregate", "hh_sum", "meas", "hh_main", "hh_support", "hh_chain", "hh_final")
+KERNELS = ("parse", "expand", "hash", "query", "aggregate", "hh_sum", "meas", "hh_main", "hh_support", "hh_chain", "hh_final", "prove")
 
 
 class Prio3:
@@ -198,6 +198,20 @@ class Prio3:
                                          num_shares, n, ver.ctypes.data, status.ctypes.data), "flp_query_batch")
         self.n_last = n
         return ver, status
+
+    def flp_prove(self, inputs, prove_rands, joint_rands):
+        """Type::prove on the GPU for n tuples: uint8 [n, input_len*16], [n, arity*16], [n, joint_rand_len*16]
+        -> (proofs uint8 [n, proof_len*16], status int32 [n])."""
+        s = self.sizes
+        a = np.ascontiguousarray(inputs, dtype=np.uint8).reshape(-1, 16 * s.input_len)
+        n = a.shape[0]
+        pr = np.ascontiguousarray(prove_rands, dtype=np.uint8).reshape(n, 16 * s.arity)
+        jr = np.ascontiguousarray(joint_rands, dtype=np.uint8).reshape(n, 16 * s.joint_rand_len)
+        out = np.zeros((n, 16 * s.proof_len), np.uint8)
+        status = np.zeros(n, np.int32)
+        self._chk(lib.wh_flp_prove_batch(self._ctx, a.ctypes.data, pr.ctypes.data, jr.ctypes.data, n, out.ctypes.data,
+                                         status.ctypes.data), "flp_prove_batch")
+        return out, status
 
     def flp_decide(self, verifiers):
         v = np.ascontiguousarray(verifiers, dtype=np.uint8)
