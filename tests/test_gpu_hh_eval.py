@@ -113,11 +113,13 @@ def test_key_format_errors_and_padding():
     h.close()
 
 
-def test_sub_batches_and_device_entry():
-    """The device-pointer entry point with caller-owned buffers, more key chains than one sub-batch of scratch would hold
-    is not reachable at test sizes, so this checks the plain path at a larger n and the accumulate form of the sum."""
+def test_sub_batches_and_device_entry(monkeypatch):
+    """The device-pointer entry point with caller-owned buffers; WH_HH_SUBBATCH makes the 300 key chains take five
+    sub-batches of scratch (the last one partial), more workgroups than CUs walk the persistent loop, and the sum runs in
+    its accumulate form."""
     import torch
     from whisper_amd import hh
+    monkeypatch.setenv("WH_HH_SUBBATCH", "64")
     depth, n = 4, 300
     vk = bytes(range(16))
     rng = np.random.default_rng(1)
@@ -180,3 +182,23 @@ def test_server_hh_flow_with_group_test():
         if i not in bad:
             want[alphas[i]] += bks[i]
     assert ((sketches[0] + sketches[1]) == want).all()
+
+
+def test_many_key_chains_per_cu_and_mixed_validity():
+    """More key chains than CUs, so every persistent workgroup takes several and its producer wavefront prepares key
+    chain k + G while k is converted; malformed ones in between must not disturb their neighbours."""
+    from whisper_amd import hh
+    depth, n = 3, 700
+    vk = bytes(range(50, 66))
+    rng = np.random.default_rng(99)
+    A0, _, _, _ = _make(depth, 16, 321)
+    keys = A0[rng.integers(0, 16, n)].copy()
+    keys[:, :8] = np.arange(n, dtype=np.uint64).view(np.uint8).reshape(n, 8)
+    broken = rng.choice(n, 40, replace=False)
+    for k, i in enumerate(broken):
+        at = (16, 33, keys.shape[1] - 111 + 17, 41 + 18 * depth + 64)[k % 4]
+        keys[i, at] = 9
+    h = hh.HeavyHitters(1 << depth)
+    tags, ids, status, dat = _check_against_oracle(h, vk, keys, depth)
+    assert set(np.nonzero(status)[0]) == set(int(i) for i in broken)
+    h.close()

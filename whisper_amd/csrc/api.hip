@@ -743,6 +743,10 @@ int32_t wh_hh_eval_and_check_batch_dev(wh_ctx *c, const uint8_t verify_key[16], 
     // sub-batches bound the scratch (64 B per leaf for the proof chain): at most 16384 key chains or 2 GiB at a time
     uint64_t cap = (2ull << 30) / (64ull << depth);
     if (cap > 16384) cap = 16384;
+    if (const char *e = getenv("WH_HH_SUBBATCH")) {       // tuning / test knob: key chains per sub-batch
+        const uint64_t v = strtoull(e, nullptr, 10);
+        if (v >= 1 && v < cap) cap = v;
+    }
     if (cap > n) cap = n ? n : 1;
     if ((rc = hh_workspace(c, cap, depth))) return rc;
     c->d_hh_dat_last = d_dat; c->hh_n_last = n; c->hh_depth_last = depth;
