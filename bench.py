@@ -323,6 +323,16 @@ def bench_hh(args, rank, local_rank, world, dev, backend):
         aes_main = 2 * (N - 1) + 2 * N + 65 * N + 1
         issue_cycles = 160 * (4.2 + 2.6) + 16 * 2.6 + 80 * 2.3    # per block and wavefront on one of 4 SIMDs (tools/aes_microbench.hip)
         aes_peak = 256 * 2.4e9 * 4 * 64 / issue_cycles
+        traffic, traffic_src = None, None        # PMC passes committed under profiles/ (tools/hh_pmc.sh), same workload and size only
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            ent = pmc.get(args.workload)
+            if ent and ent["key_chains_per_gpu"] == n:
+                traffic = ent["kernels"]["k_hh_main"]["fetch_bytes"] + ent["kernels"]["k_hh_main"]["write_bytes"]
+                traffic_src = pmc["source"]
+        except (OSError, ValueError, KeyError):
+            pass
         value = world * n * args.steps / elapsed
         result = {
             "metric": "expanded+aggregated heavy-hitter key chains/sec (node), eval_and_check + sketch sums",
@@ -334,7 +344,8 @@ def bench_hh(args, rank, local_rank, world, dev, backend):
                        "inputs": "resident in HBM", "status_nonzero": n_bad_status, "client_gen_s": round(t_gen, 2),
                        "parallelism": f"key chains sharded over {world} GPU(s); integer all-reduce of the sketches"},
             "roofline": {"bound": "hbm", "kernel": "k_hh_main", "achieved": main_bytes / (main_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": main_bytes / (main_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": main_bytes / (main_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "avg_launch_ms": main_ms, "alg_bytes_per_launch": main_bytes,
                          "note": "table-driven AES is bound by instruction issue, not by HBM; see valu"},
             "valu": {"aes_blocks_per_step": n * aes_all, "aes_blocks_per_s": n * aes_all * args.steps / elapsed * world,
