@@ -115,3 +115,27 @@ def test_no_gpu_fails_loudly():
         pytest.skip("GPU present")
     with pytest.raises(W.WhError):
         W.new_sum_vec_256(2, 16, 8, 4)
+
+
+def test_bucket_recover_like_the_reference():
+    """hhcore/src/bucket.rs:153-207 (test_bucket_recover) with seeded noise: the string with the most votes in a bucket
+    is read back, sign handling included; and a sketch reads back only strings that hash to their own bucket."""
+    from whisper_amd import hh
+    s1, s2 = b"hello my name is curious george!", b"asdfiej;lj2938psh,mcs932shdfpqw8"
+    rng = np.random.default_rng(0)
+    noise = lambda: hh.bytes_to_bucket(bytes(rng.integers(48, 122, 32, dtype=np.uint8)), bool(rng.integers(0, 2)))
+    b = (100 * hh.bytes_to_bucket(s1, False) + 60 * hh.bytes_to_bucket(s2, True)).astype(np.uint32)
+    for _ in range(30):
+        b = (b + noise()).astype(np.uint32)
+    assert hh.recover_bucket(b) == s1
+    b = (b + 160 * hh.bytes_to_bucket(s2, True)).astype(np.uint32)
+    for _ in range(80):
+        b = (b + noise()).astype(np.uint32)
+    assert hh.recover_bucket(b) == s2
+    # CountSketch::recover: one heavy string in its own bucket of a 64-bucket sketch, repetition 3
+    sign, idx = hh.get_sign_and_bkt(s1, 64, 3)
+    sk = np.zeros((64, 258), np.uint32)
+    sk[idx] = 50 * hh.bytes_to_bucket(s1, sign)
+    sk[(idx + 1) % 64] = 50 * hh.bytes_to_bucket(s1, sign)        # the same votes in the wrong bucket are not reported
+    assert hh.recover(sk, 49, 3) == {s1}
+    assert hh.recover(sk, 50, 3) == set()

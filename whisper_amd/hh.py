@@ -6,6 +6,7 @@ Names follow the Rust crates: `BCSketch::gen_key_chain` / `eval_and_check` (hhco
 receive (serialize/src/lib.rs:72-80); `eval_and_check` runs over a whole batch, as the GPU wants it.
 """
 import ctypes as C
+import hashlib
 
 import numpy as np
 
@@ -38,6 +39,50 @@ def gen_key_chain(depth, client_id, alpha, bucket, rng_seed):
     if rc:
         raise WhError(rc, "gen_key_chain")
     return k0, k1
+
+
+# ---- host side of the sketch: what the clients put in and what the servers read out (no GPU work) ----
+def get_sign_and_bkt(v, num_buckets, rep_count):
+    """hhcore/src/lib.rs:15-24: SHA-256(v || rep_count as u16 LE) -> (sign, bucket index)."""
+    h = hashlib.sha256(bytes(v) + int(rep_count).to_bytes(2, "little")).digest()
+    return bool(h[0] & 1), int.from_bytes(h[3:11], "little") % num_buckets
+
+
+def bytes_to_bucket(s, sign):
+    """hhcore/src/utils.rs:43-66: one counter per bit of the string (bits of a byte LSB first, common/src/lib.rs:172-226),
+    +1 / -1 by the bit and flipped when `sign` is false; sign_data = +1 / -1; ctr = 1.  uint32[258]."""
+    bits = np.unpackbits(np.frombuffer(bytes(s), np.uint8), bitorder="little")
+    if bits.size != BUCKET_WORDS - 2:
+        raise ValueError("client strings are 32 bytes")
+    one, minus = np.uint32(1), np.uint32(0xffffffff)
+    out = np.empty(BUCKET_WORDS, np.uint32)
+    out[:256] = np.where(bits == 1, one if sign else minus, minus if sign else one)
+    out[256] = one if sign else minus
+    out[257] = 1
+    return out
+
+
+def _positive(v):
+    return v < (1 << 16)                     # Ordered for u32, common/src/group.rs:139-142
+
+
+def recover_bucket(bucket):
+    """Bucket::recover + bits_to_bytes (hhcore/src/bucket.rs:112-120, common/src/lib.rs:208-217) -> 32 bytes."""
+    b = np.asarray(bucket, np.uint32)
+    bits = _positive(b[:256]) if _positive(b[256]) else ~_positive(b[:256])
+    return np.packbits(bits.astype(np.uint8), bitorder="little").tobytes()
+
+
+def recover(sketch, threshold, rep_count):
+    """CountSketch::recover (hhcore/src/countsketch.rs:30-46): the strings of the buckets whose counter exceeds the
+    threshold and that hash back to their own bucket.  sketch: uint32 [num_buckets, 258] (both servers' sketches added)."""
+    sk = np.asarray(sketch, np.uint32)
+    out = set()
+    for i in np.nonzero(sk[:, 257] > np.uint32(threshold))[0]:
+        cand = recover_bucket(sk[i])
+        if get_sign_and_bkt(cand, sk.shape[0], rep_count)[1] == i:
+            out.add(cand)
+    return out
 
 
 class HeavyHitters:
