@@ -28,3 +28,12 @@ def test_run_vdaf_prepare_cpp_two_servers():
     servers, aggregate shares unshard to the honest sum."""
     r = subprocess.run([_binary("test_run_vdaf_prepare")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_server_hh_cpp_two_servers():
+    """One server-hh repetition (server-hh/src/main.rs:53-110, 255-282) on two GPU contexts through the C++ host mirror:
+    malformed clients rejected by both servers (String tags, SHA-256 batch proofs), sketches merge to the honest votes,
+    the heavy string is read back (CountSketch::recover)."""
+    r = subprocess.run([_binary("test_server_hh")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
