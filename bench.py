@@ -321,8 +321,11 @@ def bench_hh(args, rank, local_rank, world, dev, backend):
         # 14 per support key, testing id; in k_hh_main: all but the chain and the support keys
         aes_all = 2 * (N - 1) + 2 * N + 65 * N + 4 * N + 257 * 14 + 1
         aes_main = 2 * (N - 1) + 2 * N + 65 * N + 1
-        issue_cycles = 160 * (4.2 + 2.6) + 16 * 2.6 + 80 * 2.3    # per block and wavefront on one of 4 SIMDs (tools/aes_microbench.hip)
-        aes_peak = 256 * 2.4e9 * 4 * 64 / issue_cycles
+        # two bounds of the table AES, both from tools/aes_microbench.hip: instruction issue (per block and wavefront
+        # 160 x (v_perm 4.2 + ds_read 2.6) + 16 x 2.6 + 80 x 2.3 cycles on one of 4 SIMDs) and the LDS itself
+        # (176 ds_read_b32 per block, a CU serves 32 lanes per clock); the lower one binds
+        issue_cycles = 160 * (4.2 + 2.6) + 16 * 2.6 + 80 * 2.3
+        aes_peak = min(256 * 2.4e9 * 4 * 64 / issue_cycles, 256 * 2.4e9 * 32 / 176)
         traffic, traffic_src = None, None        # PMC passes committed under profiles/ (tools/hh_pmc.sh), same workload and size only
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
@@ -349,10 +352,11 @@ def bench_hh(args, rank, local_rank, world, dev, backend):
                          "avg_launch_ms": main_ms, "alg_bytes_per_launch": main_bytes,
                          "note": "table-driven AES is bound by instruction issue, not by HBM; see valu"},
             "valu": {"aes_blocks_per_step": n * aes_all, "aes_blocks_per_s": n * aes_all * args.steps / elapsed * world,
-                     "k_hh_main_aes_blocks_per_s": n * aes_main / (main_ms * 1e-3), "aes_issue_bound_blocks_per_s": aes_peak,
+                     "k_hh_main_aes_blocks_per_s": n * aes_main / (main_ms * 1e-3), "aes_bound_blocks_per_s": aes_peak,
                      "frac": n * aes_main / (main_ms * 1e-3) / aes_peak,
-                     "note": "bound = 160 x (v_perm_b32 4.2 + ds_read_b32 2.6) + 16 x 2.6 + 80 x 2.3 issue cycles per block and "
-                             "wavefront; VALU and LDS instructions of a wavefront's SIMD do not overlap "
+                     "note": "bound = the lower of the LDS rate (176 table reads per block at 32 lanes/clk/CU: 111.7 G blocks/s) and "
+                             "instruction issue (160 x (v_perm_b32 4.2 + ds_read_b32 2.6) + 16 x 2.6 + 80 x 2.3 cycles per block and "
+                             "wavefront; VALU and LDS instructions of a SIMD do not overlap: 119.7 G blocks/s) "
                              "(tools/aes_microbench.hip, profiles/r1_aes_microbench.txt); frac is k_hh_main's"},
             "kernels": kernels,
         }
