@@ -227,6 +227,16 @@ int32_t wh_client_shard_many(const wh_prio3_params *params, const uint64_t *meas
                              const uint8_t *nonces, const uint8_t *rands, uint64_t first_client_id, uint64_t n,
                              uint32_t nthreads, uint8_t *leader_reports, uint8_t *helper_reports);
 
+/* replaces: the same Prio3::shard_batched + VdafBatchedKey::get_encoded for n clients ON THE GPU (vdaf/prio3.rs:537-991,
+ * vdaf.rs:148-162): measurement encoding, share / prove-randomness expansion, both proofs (Type::prove), the joint- and
+ * query-randomness Fiat-Shamir parts, both public proofs (Type::query with num_shares = 1) and the report encoding.  Same
+ * arguments and byte-identical reports as wh_client_shard_many; for a meta-client that must make millions of DISTINCT
+ * valid reports (client-batch-prio3/src/main.rs:67-153).  Circuits with at most 511 gadget calls.  Uses the context's
+ * verification workspace: results of an earlier prepare call on `ctx` (out shares, status) are gone afterwards. */
+int32_t wh_client_shard_many_gpu(wh_ctx *ctx, const uint64_t *measurements, uint32_t meas_words, const uint8_t *nonces,
+                                 const uint8_t *rands, uint64_t first_client_id, uint64_t n, uint8_t *leader_reports,
+                                 uint8_t *helper_reports);
+
 /* replaces (CPU, client side): BCSketch::gen_key_chain (hhcore/src/protocol.rs:31-76) for IntModN<2^depth> -- VDPFKey::gen
  * (hhcore/src/vdpf.rs:54-113) of the main key and of the 257 support keys -- and bincode serialisation.  bucket: 256 data
  * + sign_data (each 1 or -1 mod 2^32) + ctr; thread_rng is replaced by SHAKE128(rng_seed).  Writes both servers' key chains. */

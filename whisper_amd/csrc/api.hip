@@ -10,6 +10,7 @@
 #include "aes_host.hpp"
 #include "hh_dev.hpp"
 #include "prove_dev.hpp"
+#include "shard_dev.hpp"
 #include "kernels.hip"
 
 using namespace wh;
@@ -450,11 +451,9 @@ int32_t wh_prio3_prepare_finish_batch(wh_ctx *c, const uint8_t *const *prep_shar
     return rc;
 }
 
-int32_t wh_flp_query_batch(wh_ctx *c, const uint8_t *input, const uint8_t *proof, const uint8_t *query_rand,
-                           const uint8_t *joint_rand, uint32_t num_shares, uint64_t n, uint8_t *verifier, int32_t *status) {
-    if (!c || !num_shares || (n && (!input || !proof || !query_rand || !joint_rand || !verifier || !status))) return WH_ERR_PARAM;
-    if (n > 0xfffffff0ull) return WH_ERR_PARAM;
-    HIPCHK(c, hipSetDevice(c->device));
+// Type::query on rows already in HBM: d_in[n][input_len], d_pf[n][proof_len], d_qr[n][1], d_jr[n][jr_len] -> d_ver[n][verifier_len]
+static int32_t flp_query_dev(wh_ctx *c, const uint8_t *d_in, const uint8_t *d_pf, const uint8_t *d_qr, const uint8_t *d_jr,
+                             uint32_t num_shares, uint64_t n, uint8_t *d_ver, int32_t *d_status) {
     const HostSizes &z = c->z;
     int32_t rc;
     c->P.mode = 2; c->P.ver_stride = z.verifier_len;
@@ -466,39 +465,47 @@ int32_t wh_flp_query_batch(wh_ctx *c, const uint8_t *input, const uint8_t *proof
     if (!n) return WH_OK;
     const QueryLaunch q = query_launch(c, true);
     if (!q.fn) { c->err = "circuit has too many gadget calls for the query kernel's LDS rows"; return WH_ERR_UNSUPPORTED; }
+    HIPCHK(c, hipMemsetAsync(c->W.counters, 0, 64, c->stream));
+    c->d_status_last = d_status;
+    const uint32_t nb = (uint32_t)n, npad = (nb + 255) / 256 * 256;
+    hipLaunchKernelGGL(k_flp_setup, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, d_in, d_pf, d_qr, d_jr, nb, d_status);
+    hipLaunchKernelGGL(q.fn, dim3(q.polyeval ? (nb + 3) / 4 : nb), dim3(64 * q.waves), q.lds, c->stream, c->P, c->W, d_ver,
+                       reinterpret_cast<uint8_t *>(c->d_out_shares), d_status);
+    HIPCHK(c, hipGetLastError());
+    return WH_OK;
+}
+
+int32_t wh_flp_query_batch(wh_ctx *c, const uint8_t *input, const uint8_t *proof, const uint8_t *query_rand,
+                           const uint8_t *joint_rand, uint32_t num_shares, uint64_t n, uint8_t *verifier, int32_t *status) {
+    if (!c || !num_shares || (n && (!input || !proof || !query_rand || !joint_rand || !verifier || !status))) return WH_ERR_PARAM;
+    if (n > 0xfffffff0ull) return WH_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    const HostSizes &z = c->z;
+    int32_t rc;
     const uint64_t in_b = 16ull * z.input_len * n, pf_b = 16ull * z.proof_len * n, jr_b = 16ull * z.jr_len * n, ver_b = 16ull * z.verifier_len * n;
     if ((rc = ensure(c, c->d_blob, c->blob_cap, in_b + pf_b + 16 * n + jr_b + 64))) return rc;
-    if ((rc = ensure(c, c->d_prep, c->prep_cap, ver_b))) return rc;
-    if ((rc = ensure(c, c->d_status_own, c->status_cap, n))) return rc;
+    if ((rc = ensure(c, c->d_prep, c->prep_cap, ver_b ? ver_b : 16))) return rc;
+    if ((rc = ensure(c, c->d_status_own, c->status_cap, n ? n : 1))) return rc;
     uint8_t *d_in = c->d_blob, *d_pf = d_in + in_b, *d_qr = d_pf + pf_b, *d_jr = d_qr + 16 * n;
-    HIPCHK(c, hipMemcpyAsync(d_in, input, in_b, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d_pf, proof, pf_b, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d_qr, query_rand, 16 * n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d_jr, joint_rand, jr_b, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->W.counters, 0, 64, c->stream));
-    c->d_status_last = c->d_status_own;
-    const uint32_t nb = (uint32_t)n, npad = (nb + 255) / 256 * 256;
-    hipLaunchKernelGGL(k_flp_setup, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, d_in, d_pf, d_qr, d_jr, nb, c->d_status_own);
-    hipLaunchKernelGGL(q.fn, dim3(q.polyeval ? (nb + 3) / 4 : nb), dim3(64 * q.waves), q.lds, c->stream, c->P, c->W, c->d_prep,
-                       reinterpret_cast<uint8_t *>(c->d_out_shares), c->d_status_own);
-    HIPCHK(c, hipGetLastError());
+    if (n) {
+        HIPCHK(c, hipMemcpyAsync(d_in, input, in_b, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_pf, proof, pf_b, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_qr, query_rand, 16 * n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_jr, joint_rand, jr_b, hipMemcpyHostToDevice, c->stream));
+    }
+    if ((rc = flp_query_dev(c, d_in, d_pf, d_qr, d_jr, num_shares, n, c->d_prep, c->d_status_own))) return rc;
+    if (!n) return WH_OK;
     HIPCHK(c, hipMemcpyAsync(verifier, c->d_prep, ver_b, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(status, c->d_status_own, 4 * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return WH_OK;
 }
 
-int32_t wh_flp_prove_batch(wh_ctx *c, const uint8_t *input, const uint8_t *prove_rand, const uint8_t *joint_rand, uint64_t n,
-                           uint8_t *proof, int32_t *status) {
-    if (!c || (n && (!input || !prove_rand || !proof || !status)) || (n && c->z.jr_len && !joint_rand)) return WH_ERR_PARAM;
-    if (n > 0x7fffffffull) return WH_ERR_PARAM;
-    HIPCHK(c, hipSetDevice(c->device));
+// transform tables of the prover, built on first use: w_2m^k, and the twist w_2m^bitrev(pos) / m that turns coefficients into
+// the odd half of the 2m evaluations
+static int32_t prove_tables(wh_ctx *c, ProveDev &D) {
     const HostSizes &z = c->z;
-    if (z.m > PROVE_MAX_M) { c->err = "flp prove: more than 511 gadget calls do not fit the kernel's LDS"; return WH_ERR_UNSUPPORTED; }
-    if (!n) return WH_OK;
-    int32_t rc;
     if (!c->d_omega2m) {
-        // w_2m^k, and the twist w_2m^bitrev(pos) / m that turns coefficients into the odd half of the 2m evaluations
         const uint32_t m = z.m, two_m = 2 * z.m;
         std::vector<F128> om(two_m), tw(m);
         const F128 w = root_of_unity(z.log2m + 1), minv = f_inv(f_small(m));
@@ -514,8 +521,22 @@ int32_t wh_flp_prove_batch(wh_ctx *c, const uint8_t *input, const uint8_t *prove
         HIPCHK(c, hipMemcpy(c->d_omega2m, om.data(), two_m * sizeof(F128), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(c->d_twist, tw.data(), m * sizeof(F128), hipMemcpyHostToDevice));
     }
-    ProveDev D{z.input_len, c->params.chunk, z.calls, z.m, z.log2m, z.arity, z.gpoly_len, z.proof_len, z.jr_len,
-               c->d_omega2m, c->d_twist, f_inv(f_small(2ull * z.m))};
+    D = ProveDev{z.input_len, c->params.chunk, z.calls, z.m, z.log2m, z.arity, z.gpoly_len, z.proof_len, z.jr_len,
+                 c->d_omega2m, c->d_twist, f_inv(f_small(2ull * z.m))};
+    return WH_OK;
+}
+
+int32_t wh_flp_prove_batch(wh_ctx *c, const uint8_t *input, const uint8_t *prove_rand, const uint8_t *joint_rand, uint64_t n,
+                           uint8_t *proof, int32_t *status) {
+    if (!c || (n && (!input || !prove_rand || !proof || !status)) || (n && c->z.jr_len && !joint_rand)) return WH_ERR_PARAM;
+    if (n > 0x7fffffffull) return WH_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    const HostSizes &z = c->z;
+    if (z.m > PROVE_MAX_M) { c->err = "flp prove: more than 511 gadget calls do not fit the kernel's LDS"; return WH_ERR_UNSUPPORTED; }
+    if (!n) return WH_OK;
+    int32_t rc;
+    ProveDev D;
+    if ((rc = prove_tables(c, D))) return rc;
     const uint64_t in_b = 16ull * z.input_len * n, pr_b = 16ull * z.arity * n, jr_b = 16ull * z.jr_len * n, pf_b = 16ull * z.proof_len * n;
     if ((rc = ensure(c, c->d_blob, c->blob_cap, in_b + pr_b + jr_b + 64))) return rc;
     if ((rc = ensure(c, c->d_prep, c->prep_cap, pf_b))) return rc;
@@ -532,6 +553,93 @@ int32_t wh_flp_prove_batch(wh_ctx *c, const uint8_t *input, const uint8_t *prove
     HIPCHK(c, hipMemcpyAsync(status, c->d_status_own, 4 * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return WH_OK;
+}
+
+// Prio3::shard_batched for n clients on the GPU (shard.hip + the prover + the query kernels), byte for byte what
+// wh_client_shard_many writes.  Uses the context's query workspace: the state of an earlier prepare call is gone afterwards.
+int32_t wh_client_shard_many_gpu(wh_ctx *c, const uint64_t *measurements, uint32_t meas_words, const uint8_t *nonces,
+                                 const uint8_t *rands, uint64_t first_client_id, uint64_t n, uint8_t *leader_reports,
+                                 uint8_t *helper_reports) {
+    if (!c || (n && (!measurements || !nonces || !rands || !leader_reports || !helper_reports))) return WH_ERR_PARAM;
+    if (n > 0x7fffffffull) return WH_ERR_PARAM;
+    const HostSizes &z = c->z;
+    const wh_prio3_params &p = c->params;
+    if (p.num_aggregators != 2) return WH_ERR_PARAM;
+    if (meas_words < (p.circuit == WH_SUMVEC ? p.len : 1u)) return WH_ERR_PARAM;
+    if (z.m > PROVE_MAX_M) { c->err = "shard: more than 511 gadget calls do not fit the prover's LDS"; return WH_ERR_UNSUPPORTED; }
+    if (2 * z.jr_len > 4) { c->err = "shard: joint randomness longer than two elements per proof"; return WH_ERR_UNSUPPORTED; }
+    for (uint64_t i = 0; i < n; i++) {               // Type::encode_measurement's range checks (types.rs:246-253, 388-399, 582-606)
+        const uint64_t *m = measurements + i * meas_words;
+        if (p.circuit == WH_HISTOGRAM) { if (m[0] >= p.len) return WH_ERR_PARAM; }
+        else if (p.bits < 64)
+            for (uint32_t e = 0; e < (p.circuit == WH_SUMVEC ? p.len : 1u); e++) if (m[e] >> p.bits) return WH_ERR_PARAM;
+    }
+    if (!n) return WH_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int32_t rc;
+    ProveDev PD;
+    if ((rc = prove_tables(c, PD))) return rc;
+    ShardDev D{p.circuit, p.bits, p.len, z.input_len, z.proof_len, z.verifier_len, z.arity, z.jr_len, z.alg_id,
+               z.leader_len, z.helper_len, meas_words, c->P.sampler_bound};
+    // one arena per call: sizes per client, each region 256-byte aligned
+    const uint64_t vin = 16ull * z.input_len, vpf = 16ull * z.proof_len, var = 16ull * z.arity, vjr = 16ull * z.jr_len,
+                   vver = 16ull * z.verifier_len;
+    const uint64_t per_client = 8ull * meas_words + 16 + 144 + 2 * vin + 6 * vpf + 2 * var + 4 * vjr + 32 + 2 * vver + 64 +
+                                z.leader_len + z.helper_len + 4;
+    uint64_t sub = (8ull << 30) / per_client;
+    const uint64_t qcap = pick_cap(c, n);
+    if (sub > qcap) sub = qcap;
+    if (sub > n) sub = n;
+    if (sub < 1) sub = 1;
+    uint8_t *arena = nullptr;
+    HIPCHK(c, hipMalloc((void **)&arena, sub * per_client + 32 * 256));
+    uint8_t *cur = arena;
+    auto take = [&](uint64_t bytes) { uint8_t *r = cur; cur += (bytes + 255) / 256 * 256; return r; };
+    ShardBuf B{};
+    uint64_t *d_meas = reinterpret_cast<uint64_t *>(take(8ull * meas_words * sub));
+    uint8_t *d_nonces = take(16 * sub), *d_rands = take(144 * sub);
+    B.meas = d_meas; B.nonces = d_nonces; B.rands = d_rands;
+    B.x = take(vin * sub); B.hm = take(vin * sub);
+    for (int t = 0; t < 2; t++) { B.hp[t] = take(vpf * sub); B.pr[t] = take(var * sub); B.proof[t] = take(vpf * sub); }
+    for (int t = 0; t < 2; t++) { B.jr[t] = take(vjr * sub); B.qr[t] = take(16 * sub); B.pub[t] = take(vver * sub); }
+    B.jrf = take(2 * vjr * sub);
+    B.parts = take(64 * sub);
+    B.lrep = take((uint64_t)z.leader_len * sub); B.hrep = take((uint64_t)z.helper_len * sub);
+    int32_t *d_st = reinterpret_cast<int32_t *>(take(4 * sub));
+    std::vector<int32_t> st(sub);
+    hipError_t e = hipSuccess;
+    rc = WH_OK;
+    for (uint64_t base = 0; base < n && !rc && e == hipSuccess; base += sub) {
+        const uint64_t k = n - base < sub ? n - base : sub;
+        const uint32_t kn = (uint32_t)k;
+        B.first_id = first_client_id + base;
+        if ((e = hipMemcpyAsync(d_meas, measurements + base * meas_words, 8ull * meas_words * k, hipMemcpyHostToDevice, c->stream))) break;
+        if ((e = hipMemcpyAsync(d_nonces, nonces + 16 * base, 16 * k, hipMemcpyHostToDevice, c->stream))) break;
+        if ((e = hipMemcpyAsync(d_rands, rands + 144 * base, 144 * k, hipMemcpyHostToDevice, c->stream))) break;
+        launch_shard_stage1(D, B, kn, c->stream);
+        for (int t = 0; t < 2 && e == hipSuccess; t++)
+            e = (hipError_t)launch_flp_prove(PD, p.circuit != WH_AVERAGE, B.x, B.pr[t], B.jr[t], kn, B.proof[t], d_st, c->stream);
+        if (e) break;
+        launch_shard_stage2(D, B, kn, c->stream);
+        for (int t = 0; t < 2 && !rc; t++) {
+            if ((rc = flp_query_dev(c, B.x, B.proof[t], B.qr[t], B.jr[t], 1, k, B.pub[t], d_st))) break;
+            // a query randomness that is an m-th root of unity fails the whole call (flp.rs:413-419), as on the CPU
+            if ((e = hipMemcpyAsync(st.data(), d_st, 4 * k, hipMemcpyDeviceToHost, c->stream))) break;
+            if ((e = hipStreamSynchronize(c->stream))) break;
+            for (uint64_t i = 0; i < k && !rc; i++) if (st[i]) rc = st[i];
+        }
+        if (rc || e) break;
+        launch_shard_stage3(D, B, kn, c->stream);
+        if ((e = hipGetLastError())) break;
+        if ((e = hipMemcpyAsync(leader_reports + base * z.leader_len, B.lrep, (uint64_t)z.leader_len * k, hipMemcpyDeviceToHost, c->stream))) break;
+        if ((e = hipMemcpyAsync(helper_reports + base * z.helper_len, B.hrep, (uint64_t)z.helper_len * k, hipMemcpyDeviceToHost, c->stream))) break;
+        e = hipStreamSynchronize(c->stream);
+    }
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(arena);
+    c->n_last = 0; c->d_status_last = nullptr;        // the query kernels ran on scratch of this call
+    if (!rc && e != hipSuccess) { c->err = std::string("shard: ") + hipGetErrorString(e); rc = WH_ERR_HIP; }
+    return rc;
 }
 
 int32_t wh_flp_decide_batch(wh_ctx *c, const uint8_t *verifier, uint64_t n, int32_t *decision) {

@@ -213,6 +213,23 @@ class Prio3:
                                          status.ctypes.data), "flp_prove_batch")
         return out, status
 
+    def shard_batched_many(self, measurements, nonces, rands, first_client_id=0):
+        """Prio3::shard_batched for n clients on the GPU: same arguments and byte-identical reports as the module-level
+        shard_batched_many (the CPU client).  Overwrites the state of an earlier prepare call on this instance."""
+        meas = np.ascontiguousarray(measurements, dtype=np.uint64)
+        if meas.ndim == 1:
+            meas = meas.reshape(-1, 1)
+        n = meas.shape[0]
+        nonces = np.ascontiguousarray(nonces, dtype=np.uint8).reshape(n, 16)
+        rands = np.ascontiguousarray(rands, dtype=np.uint8).reshape(n, 144)
+        s = self.sizes
+        lr = np.zeros((n, s.leader_report_len), np.uint8)
+        hr = np.zeros((n, s.helper_report_len), np.uint8)
+        self._chk(lib.wh_client_shard_many_gpu(self._ctx, meas.ctypes.data, meas.shape[1], nonces.ctypes.data, rands.ctypes.data,
+                                               first_client_id, n, lr.ctypes.data, hr.ctypes.data), "shard_batched_many (GPU)")
+        self.n_last = 0
+        return lr, hr
+
     def flp_decide(self, verifiers):
         v = np.ascontiguousarray(verifiers, dtype=np.uint8)
         n = v.shape[0]
