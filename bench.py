@@ -6,6 +6,8 @@ One step = one pass over one batch of encoded client reports already resident in
   + wh_prio3_aggregate_dev (masked sum of out shares)
   + for N > 1: RCCL all-gather of the per-GPU partial aggregates and an on-GPU mod-p reduction.
 Reports shard across ranks with no data-path collective (weak scaling: fixed reports per GPU).
+Every report comes from a distinct synthetic client, sharded on the same GPU before the timed region
+(wh_client_shard_many_gpu, byte-identical to the CPU client); --tiled makes a few on the CPU and repeats them instead.
 
   python bench.py --gpus 1 --steps 5 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -70,7 +72,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="sumvec_large", choices=sorted(WORKLOADS) + sorted(HH_WORKLOADS))
     ap.add_argument("--reports-per-gpu", type=int, default=0)
-    ap.add_argument("--unique", type=int, default=128, help="distinct clients generated on the CPU and tiled")
+    ap.add_argument("--unique", type=int, default=128, help="with --tiled: distinct clients generated on the CPU")
+    ap.add_argument("--tiled", dest="distinct", action="store_false",
+                    help="--unique distinct clients sharded on the CPU and tiled, instead of every report from a distinct client sharded on the GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -104,20 +108,58 @@ def main():
     K = max(1, min(args.unique, n // 2 if n >= 2 else 1))
     nthreads = max(1, min(16, os.cpu_count() or 1))
 
-    # ---- synthetic clients: K distinct clients sharded on the CPU; this server sees the Leader
-    # share of even clients and the Helper share of odd ones (client-batch-prio3 main.rs:114-115)
+    vdaf = W.Prio3(params, device=local_rank)
     t_gen = time.time()
-    lr, hr, _ = make_reports(params, 2 * K, seed=1000 + rank, first_client_id=rank << 40, nthreads=nthreads)
-    tile_reports = [(lr[i] if i % 2 == 0 else hr[i]) for i in range(2 * K)]
-    tile = np.concatenate(tile_reports)
-    tile_off = np.zeros(2 * K + 1, np.int64)
-    tile_off[1:] = np.cumsum([len(r) for r in tile_reports])
+    if args.distinct:
+        # ---- synthetic clients: n DISTINCT clients sharded on this GPU (wh_client_shard_many_gpu, byte-identical to the CPU
+        # client); this server sees the Leader share of even clients and the Helper share of odd ones
+        rng = np.random.default_rng(1000 + rank)
+        if wl["circuit"] == W.SUMVEC:
+            meas = rng.integers(0, 1 << wl["bits"], (n, wl["length"]), dtype=np.uint64)
+        else:
+            meas = rng.integers(0, wl["length"], (n, 1), dtype=np.uint64)
+        nonces = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+        rands = rng.integers(0, 256, (n, 144), dtype=np.uint8)
+        L, H = s.leader_report_len, s.helper_report_len
+        d_l = torch.empty(n * L, dtype=torch.uint8, device=dev)
+        d_h = torch.empty(n * H, dtype=torch.uint8, device=dev)
+        t_shard = time.time()
+        vdaf.shard_batched_many_dev(meas, nonces, rands, rank << 40, d_l.data_ptr(), d_h.data_ptr())
+        t_shard = time.time() - t_shard
+        del meas
+        pairs = n // 2
+        d_blob = torch.empty(pairs * (L + H) + (L if n % 2 else 0) + 1, dtype=torch.uint8, device=dev)
+        v = d_blob[: pairs * (L + H)].view(pairs, L + H)
+        v[:, :L] = d_l.view(n, L)[0:2 * pairs:2]
+        v[:, L:] = d_h.view(n, H)[1:2 * pairs:2]
+        if n % 2:
+            d_blob[pairs * (L + H): pairs * (L + H) + L] = d_l.view(n, L)[n - 1]
+        idx = torch.arange(n + 1, device=dev, dtype=torch.int64)
+        d_off = ((idx // 2) * (L + H) + (idx % 2) * L).contiguous()
+        K = min(128, max(1, n // 2))
+        off_h = d_off[: 2 * K + 1].cpu().numpy()
+        head = d_blob[: int(off_h[-1])].cpu().numpy()
+        tile_reports = [head[int(off_h[i]):int(off_h[i + 1])] for i in range(2 * K)]
+        del d_l, d_h, v
+        torch.cuda.empty_cache()
+        n_distinct = n
+    else:
+        # ---- synthetic clients: K distinct clients sharded on the CPU and tiled; this server sees the Leader
+        # share of even clients and the Helper share of odd ones (client-batch-prio3 main.rs:114-115)
+        lr, hr, _ = make_reports(params, 2 * K, seed=1000 + rank, first_client_id=rank << 40, nthreads=nthreads)
+        tile_reports = [(lr[i] if i % 2 == 0 else hr[i]) for i in range(2 * K)]
+        tile = np.concatenate(tile_reports)
+        tile_off = np.zeros(2 * K + 1, np.int64)
+        tile_off[1:] = np.cumsum([len(r) for r in tile_reports])
+        reps = (n + 2 * K - 1) // (2 * K)
+        d_tile = torch.from_numpy(tile).to(dev)
+        d_blob = d_tile.repeat(reps)
+        offs = (torch.from_numpy(tile_off[:-1]).to(dev)[None, :] + (torch.arange(reps, device=dev, dtype=torch.int64) * int(tile_off[-1]))[:, None]).reshape(-1)
+        d_off = torch.cat([offs, torch.tensor([reps * int(tile_off[-1])], device=dev, dtype=torch.int64)])[: n + 1].contiguous()
+        n_distinct = min(n, 2 * K)
+        t_shard = None
+    torch.cuda.synchronize()
     t_gen = time.time() - t_gen
-    reps = (n + 2 * K - 1) // (2 * K)
-    d_tile = torch.from_numpy(tile).to(dev)
-    d_blob = d_tile.repeat(reps)
-    offs = (torch.from_numpy(tile_off[:-1]).to(dev)[None, :] + (torch.arange(reps, device=dev, dtype=torch.int64) * int(tile_off[-1]))[:, None]).reshape(-1)
-    d_off = torch.cat([offs, torch.tensor([reps * int(tile_off[-1])], device=dev, dtype=torch.int64)])[: n + 1].contiguous()
     d_tags = torch.zeros(16 * n, dtype=torch.uint8, device=dev)
     d_ids = torch.zeros(16 * n, dtype=torch.uint8, device=dev)
     d_status = torch.zeros(n, dtype=torch.int32, device=dev)
@@ -128,7 +170,6 @@ def main():
     d_total = torch.zeros(16 * s.output_len, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 
-    vdaf = W.Prio3(params, device=local_rank)
     ext = torch.cuda.ExternalStream(vdaf.stream, device=dev)
 
     def step():
@@ -214,11 +255,12 @@ def main():
             "value": value, "unit": "reports/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u128 (Field128 mod p) + u64 (Keccak lanes)", "data": "synthetic",
-            "config": {"workload": wl["desc"], "reports_per_gpu": n, "distinct_clients_tiled": 2 * K,
+            "config": {"workload": wl["desc"], "reports_per_gpu": n, "distinct_clients": n_distinct, "clients_made_on": "gpu (wh_client_shard_many_gpu)" if args.distinct else "cpu, tiled",
                        "leader_report_bytes": s.leader_report_len, "helper_report_bytes": s.helper_report_len,
                        "roles": "alternating Leader/Helper", "inputs": "resident in HBM",
                        "parallelism": f"reports sharded over {world} GPU(s); all-gather + mod-p reduce of partial aggregates",
-                       "status_nonzero": n_bad_status, "client_gen_s": round(t_gen, 2)},
+                       "status_nonzero": n_bad_status, "client_gen_s": round(t_gen, 2),
+                       "gpu_shard_clients_per_s": round(n / t_shard) if t_shard else None},
             "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": avg_ms, "alg_bytes_per_launch": bytes_per_launch,

@@ -232,7 +232,9 @@ int32_t wh_client_shard_many(const wh_prio3_params *params, const uint64_t *meas
  * query-randomness Fiat-Shamir parts, both public proofs (Type::query with num_shares = 1) and the report encoding.  Same
  * arguments and byte-identical reports as wh_client_shard_many; for a meta-client that must make millions of DISTINCT
  * valid reports (client-batch-prio3/src/main.rs:67-153).  Circuits with at most 511 gadget calls.  Uses the context's
- * verification workspace: results of an earlier prepare call on `ctx` (out shares, status) are gone afterwards. */
+ * verification workspace: results of an earlier prepare call on `ctx` (out shares, status) are gone afterwards.
+ * measurements, nonces and rands are host buffers; leader_reports and helper_reports may be host or device memory
+ * (a verifier bench keeps them in HBM). */
 int32_t wh_client_shard_many_gpu(wh_ctx *ctx, const uint64_t *measurements, uint32_t meas_words, const uint8_t *nonces,
                                  const uint8_t *rands, uint64_t first_client_id, uint64_t n, uint8_t *leader_reports,
                                  uint8_t *helper_reports);

@@ -556,7 +556,7 @@ int32_t wh_flp_prove_batch(wh_ctx *c, const uint8_t *input, const uint8_t *prove
 }
 
 // Prio3::shard_batched for n clients on the GPU (shard.hip + the prover + the query kernels), byte for byte what
-// wh_client_shard_many writes.  Uses the context's query workspace: the state of an earlier prepare call is gone afterwards.
+// wh_client_shard_many writes.  The two report buffers may be host or device memory (hipMemcpyDefault).  Uses the context's query workspace: the state of an earlier prepare call is gone afterwards.
 int32_t wh_client_shard_many_gpu(wh_ctx *c, const uint64_t *measurements, uint32_t meas_words, const uint8_t *nonces,
                                  const uint8_t *rands, uint64_t first_client_id, uint64_t n, uint8_t *leader_reports,
                                  uint8_t *helper_reports) {
@@ -631,8 +631,8 @@ int32_t wh_client_shard_many_gpu(wh_ctx *c, const uint64_t *measurements, uint32
         if (rc || e) break;
         launch_shard_stage3(D, B, kn, c->stream);
         if ((e = hipGetLastError())) break;
-        if ((e = hipMemcpyAsync(leader_reports + base * z.leader_len, B.lrep, (uint64_t)z.leader_len * k, hipMemcpyDeviceToHost, c->stream))) break;
-        if ((e = hipMemcpyAsync(helper_reports + base * z.helper_len, B.hrep, (uint64_t)z.helper_len * k, hipMemcpyDeviceToHost, c->stream))) break;
+        if ((e = hipMemcpyAsync(leader_reports + base * z.leader_len, B.lrep, (uint64_t)z.leader_len * k, hipMemcpyDefault, c->stream))) break;
+        if ((e = hipMemcpyAsync(helper_reports + base * z.helper_len, B.hrep, (uint64_t)z.helper_len * k, hipMemcpyDefault, c->stream))) break;
         e = hipStreamSynchronize(c->stream);
     }
     (void)hipStreamSynchronize(c->stream);

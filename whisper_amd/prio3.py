@@ -230,6 +230,18 @@ class Prio3:
         self.n_last = 0
         return lr, hr
 
+    def shard_batched_many_dev(self, measurements, nonces, rands, first_client_id, d_leader_reports, d_helper_reports):
+        """The same, reports written to device buffers [n, leader_report_len] and [n, helper_report_len] (raw pointers)."""
+        meas = np.ascontiguousarray(measurements, dtype=np.uint64)
+        if meas.ndim == 1:
+            meas = meas.reshape(-1, 1)
+        n = meas.shape[0]
+        nonces = np.ascontiguousarray(nonces, dtype=np.uint8).reshape(n, 16)
+        rands = np.ascontiguousarray(rands, dtype=np.uint8).reshape(n, 144)
+        self._chk(lib.wh_client_shard_many_gpu(self._ctx, meas.ctypes.data, meas.shape[1], nonces.ctypes.data, rands.ctypes.data,
+                                               first_client_id, n, d_leader_reports, d_helper_reports), "shard_batched_many (GPU)")
+        self.n_last = 0
+
     def flp_decide(self, verifiers):
         v = np.ascontiguousarray(verifiers, dtype=np.uint8)
         n = v.shape[0]
