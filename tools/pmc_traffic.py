@@ -6,13 +6,19 @@ from collections import defaultdict
 
 
 def per_kernel(d):
-    acc = defaultdict(list)
+    """average per launch; instantiations of one template that both ran are kept apart (k_query_psum<false, false> is the
+    verifier's launch, <false, true> the sharder's public proofs), a lone instantiation goes by the bare name"""
+    acc = defaultdict(lambda: defaultdict(list))
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            m = re.search(r"\b(k_[a-z0-9_]+)", row["Kernel_Name"])
+            m = re.search(r"\b(k_[a-z0-9_]+)(<[^>]*>)?", row["Kernel_Name"])
             if m:
-                acc[m.group(1)].append(float(row["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in acc.items()}
+                acc[m.group(1)][m.group(2) or ""].append(float(row["Counter_Value"]))
+    out = {}
+    for base, inst in acc.items():
+        for targs, v in inst.items():
+            out[base + (targs if len(inst) > 1 else "")] = sum(v) / len(v)
+    return out
 
 
 fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
