@@ -586,7 +586,7 @@ int32_t wh_client_shard_many_gpu(wh_ctx *c, const uint64_t *measurements, uint32
                    vver = 16ull * z.verifier_len;
     const uint64_t per_client = 8ull * meas_words + 16 + 144 + 2 * vin + 6 * vpf + 2 * var + 4 * vjr + 32 + 2 * vver + 64 +
                                 z.leader_len + z.helper_len + 4;
-    uint64_t sub = (8ull << 30) / per_client;
+    uint64_t sub = (24ull << 30) / per_client;         // one-lane-per-client kernels want many clients per launch; HBM is 288 GB
     const uint64_t qcap = pick_cap(c, n);
     if (sub > qcap) sub = qcap;
     if (sub > n) sub = n;
