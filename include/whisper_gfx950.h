@@ -200,6 +200,17 @@ int32_t wh_hh_buckets(wh_ctx *ctx, uint32_t *dat);
 int32_t wh_hh_aggregate(wh_ctx *ctx, const uint8_t *keep, uint32_t *acc);
 int32_t wh_hh_aggregate_dev(wh_ctx *ctx, const uint8_t *d_keep, uint32_t *d_acc, int32_t accumulate);
 
+/* ---- ordering for the group test ---- */
+/* replaces: `tags_and_shares.sort_by(|a, b| a.0.testing_id.cmp(&b.0.testing_id))` and its par_sort_by forms
+ * (server-batch-prio3/src/main.rs:93, 158; server-hh/src/main.rs:175, 266): the STABLE sort of a batch by its u128 testing
+ * ids, on the ids the prepare / eval_and_check call left in HBM.  d_ids[n][16] little endian.  Writes d_order[n]: position k
+ * of the sorted batch holds report d_order[k] (equal ids keep their input order).  If non-NULL, d_sorted_ids[n][16] and
+ * d_sorted_tags[n][tag_bytes] receive the ids and the tags (16-byte Prio3 tags, 64-byte heavy-hitter proof strings; tag_bytes
+ * a multiple of 16) in that order, ready for the host's general_binary_split_test.  n <= 2^28.  Asynchronous on the context
+ * stream. */
+int32_t wh_sort_by_testing_id_dev(wh_ctx *ctx, const uint8_t *d_ids, uint64_t n, uint32_t *d_order, const uint8_t *d_tags,
+                                  uint32_t tag_bytes, uint8_t *d_sorted_ids, uint8_t *d_sorted_tags);
+
 int32_t wh_ctx_synchronize(wh_ctx *ctx);
 
 /* ---- measurement ---- */
@@ -208,7 +219,8 @@ int32_t wh_ctx_synchronize(wh_ctx *ctx);
  * the context stream; wh_ctx_kernel_times synchronises and returns accumulated milliseconds and
  * launch counts per kernel (indices WH_K_*), optionally resetting them. */
 enum { WH_K_PARSE = 0, WH_K_EXPAND = 1, WH_K_HASH = 2, WH_K_QUERY = 3, WH_K_AGG = 4, WH_K_HH = 5, WH_K_MEAS = 6,
-       WH_K_HH_MAIN = 7, WH_K_HH_SUPPORT = 8, WH_K_HH_CHAIN = 9, WH_K_HH_FINAL = 10, WH_K_PROVE = 11, WH_NUM_KERNELS = 12 };
+       WH_K_HH_MAIN = 7, WH_K_HH_SUPPORT = 8, WH_K_HH_CHAIN = 9, WH_K_HH_FINAL = 10, WH_K_PROVE = 11, WH_K_SORT = 12,
+       WH_NUM_KERNELS = 13 };
 int32_t wh_ctx_set_profiling(wh_ctx *ctx, int32_t on);
 int32_t wh_ctx_kernel_times(wh_ctx *ctx, double *ms, uint64_t *launches, int32_t reset);
 

@@ -1,0 +1,76 @@
+"""The servers' sort by testing id (server-batch-prio3/src/main.rs:93, 158; server-hh/src/main.rs:175, 266: a stable sort on
+a u128) on the GPU, against numpy's stable lexicographic sort: permutation, sorted ids and gathered tags, bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+import whisper_amd as W
+from whisper_amd import hh
+
+pytestmark = pytest.mark.gpu
+
+
+def expected_order(ids):
+    v = ids.view(np.uint64).reshape(-1, 2)          # little endian: column 0 = low half
+    return np.lexsort((v[:, 0], v[:, 1])).astype(np.uint32)      # stable; last key is the primary one
+
+
+def run(ctx, ids, tags):
+    dev = torch.device("cuda:0")
+    n = ids.shape[0]
+    d_ids = torch.from_numpy(ids.copy()).to(dev)
+    d_tags = torch.from_numpy(tags.copy()).to(dev)
+    d_order = torch.full((max(n, 1),), -1, dtype=torch.int32, device=dev)
+    d_sids = torch.zeros_like(d_ids)
+    d_stags = torch.zeros_like(d_tags)
+    torch.cuda.synchronize()
+    ctx.sort_by_testing_id_dev(d_ids.data_ptr(), n, d_order.data_ptr(), d_tags.data_ptr(), tags.shape[1], d_sids.data_ptr(), d_stags.data_ptr())
+    ctx.synchronize()
+    return d_order.cpu().numpy().view(np.uint32)[:n], d_sids.cpu().numpy(), d_stags.cpu().numpy()
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 1023, 1024, 1025, 5000, 125_000, 1_000_003])
+def test_sort_matches_stable_host_sort(n):
+    rng = np.random.default_rng(n + 1)
+    ids = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    if n >= 64:
+        ids[n // 3: n // 3 + 20] = ids[0]                 # duplicates: the sort must keep their input order
+        ids[n // 2: n // 2 + 9, 8:] = ids[1, 8:]          # equal high halves, random low halves
+        ids[5, :] = 0
+        ids[6, :] = 255
+    tags = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    p = W.Prio3Params(W.SUMVEC, 2, 5, 3)
+    vdaf = W.Prio3(p)
+    try:
+        order, sids, stags = run(vdaf, ids, tags)
+        want = expected_order(ids)
+        assert np.array_equal(order, want)
+        assert np.array_equal(sids, ids[want]) and np.array_equal(stags, tags[want])
+    finally:
+        vdaf.close()
+
+
+def test_sort_few_distinct_ids_and_hh_tags():
+    """Heavy-hitter proof strings are 64 bytes; many equal ids exercise stability in every pass."""
+    n = 20_000
+    rng = np.random.default_rng(3)
+    pool = rng.integers(0, 256, (7, 16), dtype=np.uint8)
+    ids = pool[rng.integers(0, 7, n)]
+    tags = rng.integers(0, 256, (n, 64), dtype=np.uint8)
+    ctx = hh.HeavyHitters(512)
+    try:
+        order, sids, stags = run(ctx, ids, tags)
+        want = expected_order(ids)
+        assert np.array_equal(order, want)
+        assert np.array_equal(sids, ids[want]) and np.array_equal(stags, tags[want])
+        # the order alone (no gathers), and the documented argument checks
+        dev = torch.device("cuda:0")
+        d_ids = torch.from_numpy(ids.copy()).to(dev)
+        d_order = torch.zeros(n, dtype=torch.int32, device=dev)
+        ctx.sort_by_testing_id_dev(d_ids.data_ptr(), n, d_order.data_ptr(), None, 0, None, None)
+        ctx.synchronize()
+        assert np.array_equal(d_order.cpu().numpy().view(np.uint32), want)
+        with pytest.raises(W.WhError):
+            ctx.sort_by_testing_id_dev(d_ids.data_ptr(), n, d_order.data_ptr(), d_ids.data_ptr(), 24, None, d_ids.data_ptr())
+    finally:
+        ctx.close()

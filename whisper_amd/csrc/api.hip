@@ -11,6 +11,7 @@
 #include "hh_dev.hpp"
 #include "prove_dev.hpp"
 #include "shard_dev.hpp"
+#include "sort_dev.hpp"
 #include "kernels.hip"
 
 using namespace wh;
@@ -66,6 +67,9 @@ struct wh_ctx {
     int32_t *d_hh_status = nullptr; uint64_t hh_status_cap = 0;
     uint8_t *d_hh_keep = nullptr; uint64_t hh_keep_cap = 0;
     uint32_t *d_hh_acc = nullptr; uint64_t hh_acc_cap = 0;
+    // testing-id sort (sort.hip)
+    uint32_t *d_sort_tmp = nullptr; uint64_t sort_tmp_cap = 0;
+    uint32_t *d_sort_hist = nullptr; uint64_t sort_hist_cap = 0;
     double k_ms[WH_NUM_KERNELS] = {0};
     uint64_t k_launches[WH_NUM_KERNELS] = {0};
     std::string err;
@@ -270,7 +274,7 @@ void wh_ctx_destroy(wh_ctx *c) {
                     c->d_blob, c->d_offsets, c->d_tags, c->d_ids, c->d_prep, c->W.desc, c->W.scal, c->W.weights, c->W.wlimbs, c->W.pows, c->W.rlc,
                     c->W.hrows, c->W.hlist, c->W.llist, c->W.dirty, c->W.counters,
                     c->d_omega2m, c->d_twist, c->d_hh_tab, c->hh_w.tpc, c->hh_w.proofblk, c->hh_w.supd, c->hh_w.buckg, c->d_hh_dat, c->d_hh_keys, c->d_hh_tags,
-                    c->d_hh_ids, c->d_hh_status, c->d_hh_keep, c->d_hh_acc};
+                    c->d_hh_ids, c->d_hh_status, c->d_hh_keep, c->d_hh_acc, c->d_sort_tmp, c->d_sort_hist};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
@@ -640,6 +644,26 @@ int32_t wh_client_shard_many_gpu(wh_ctx *c, const uint64_t *measurements, uint32
     c->n_last = 0; c->d_status_last = nullptr;        // the query kernels ran on scratch of this call
     if (!rc && e != hipSuccess) { c->err = std::string("shard: ") + hipGetErrorString(e); rc = WH_ERR_HIP; }
     return rc;
+}
+
+// the servers' stable sort of a batch by testing id, on ids (and tags) already in HBM
+int32_t wh_sort_by_testing_id_dev(wh_ctx *c, const uint8_t *d_ids, uint64_t n, uint32_t *d_order, const uint8_t *d_tags,
+                                  uint32_t tag_bytes, uint8_t *d_sorted_ids, uint8_t *d_sorted_tags) {
+    if (!c || (n && (!d_ids || !d_order))) return WH_ERR_PARAM;
+    if (n > (1ull << 28)) return WH_ERR_PARAM;
+    if (d_sorted_tags && (!d_tags || !tag_bytes || tag_bytes % 16)) return WH_ERR_PARAM;
+    if (!n) return WH_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int32_t rc;
+    if ((rc = ensure(c, c->d_sort_tmp, c->sort_tmp_cap, n))) return rc;
+    if ((rc = ensure(c, c->d_sort_hist, c->sort_hist_cap, 256 * sort_blocks(n)))) return rc;
+    int e;
+    { KTimer t_(c, WH_K_SORT);
+      e = launch_sort_by_id(d_ids, (uint32_t)n, d_order, c->d_sort_tmp, c->d_sort_hist, c->stream);
+      if (!e && d_sorted_ids) e = launch_sort_gather(d_ids, 16, d_order, (uint32_t)n, d_sorted_ids, c->stream);
+      if (!e && d_sorted_tags) e = launch_sort_gather(d_tags, tag_bytes, d_order, (uint32_t)n, d_sorted_tags, c->stream); }
+    if (e) { c->err = std::string("sort launch: ") + hipGetErrorString((hipError_t)e); return WH_ERR_HIP; }
+    return WH_OK;
 }
 
 int32_t wh_flp_decide_batch(wh_ctx *c, const uint8_t *verifier, uint64_t n, int32_t *decision) {

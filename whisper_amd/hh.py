@@ -164,6 +164,11 @@ class HeavyHitters:
         fn = lib.wh_hh_bucket_accumulate_u32_dev if accumulate else lib.wh_hh_bucket_sum_u32_dev
         self._chk(fn(self._ctx, d_buckets, d_keep, n, words, d_acc), "hh_bucket_sum")
 
+    def sort_by_testing_id_dev(self, d_ids, n, d_order, d_tags=None, tag_bytes=64, d_sorted_ids=None, d_sorted_tags=None):
+        """The server's stable sort by testing id (server-hh/src/main.rs:175, 266) on device buffers (raw pointers)."""
+        self._chk(lib.wh_sort_by_testing_id_dev(self._ctx, d_ids, n, d_order, d_tags, tag_bytes, d_sorted_ids, d_sorted_tags),
+                  "sort_by_testing_id_dev")
+
     def set_profiling(self, on=True):
         self._chk(lib.wh_ctx_set_profiling(self._ctx, int(on)), "set_profiling")
 

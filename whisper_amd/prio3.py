@@ -82,7 +82,7 @@ def shard_batched_many(params, measurements, nonces, rands, first_client_id=0, n
 
 
 # indices WH_K_* of wh_ctx_kernel_times
-KERNELS = ("parse", "expand", "hash", "query", "aggregate", "hh_sum", "meas", "hh_main", "hh_support", "hh_chain", "hh_final", "prove")
+KERNELS = ("parse", "expand", "hash", "query", "aggregate", "hh_sum", "meas", "hh_main", "hh_support", "hh_chain", "hh_final", "prove", "sort")
 
 
 class Prio3:
@@ -269,6 +269,11 @@ class Prio3:
         self._chk(lib.wh_prio3_prepare_batch_dev(self._ctx, vk.ctypes.data, d_blob, d_offsets, n, d_tags, d_ids,
                                                  d_status), "prepare_batch_dev")
         self.n_last = n
+
+    def sort_by_testing_id_dev(self, d_ids, n, d_order, d_tags=None, tag_bytes=16, d_sorted_ids=None, d_sorted_tags=None):
+        """The servers' stable sort by testing id (main.rs:93) on device buffers (raw pointers); asynchronous."""
+        self._chk(lib.wh_sort_by_testing_id_dev(self._ctx, d_ids, n, d_order, d_tags, tag_bytes, d_sorted_ids, d_sorted_tags),
+                  "sort_by_testing_id_dev")
 
     def aggregate_dev(self, d_keep, d_agg):
         self._chk(lib.wh_prio3_aggregate_dev(self._ctx, d_keep, d_agg), "aggregate_dev")
