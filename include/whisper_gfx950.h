@@ -210,6 +210,8 @@ int32_t wh_hh_aggregate_dev(wh_ctx *ctx, const uint8_t *d_keep, uint32_t *d_acc,
  * stream. */
 int32_t wh_sort_by_testing_id_dev(wh_ctx *ctx, const uint8_t *d_ids, uint64_t n, uint32_t *d_order, const uint8_t *d_tags,
                                   uint32_t tag_bytes, uint8_t *d_sorted_ids, uint8_t *d_sorted_tags);
+/* the same permutation for ids in host memory (ids[n][16] in, order[n] out); synchronous */
+int32_t wh_sort_by_testing_id(wh_ctx *ctx, const uint8_t *ids, uint64_t n, uint32_t *order);
 
 int32_t wh_ctx_synchronize(wh_ctx *ctx);
 

@@ -666,6 +666,28 @@ int32_t wh_sort_by_testing_id_dev(wh_ctx *c, const uint8_t *d_ids, uint64_t n, u
     return WH_OK;
 }
 
+int32_t wh_sort_by_testing_id(wh_ctx *c, const uint8_t *ids, uint64_t n, uint32_t *order) {
+    if (!c || (n && (!ids || !order))) return WH_ERR_PARAM;
+    if (n > (1ull << 28)) return WH_ERR_PARAM;
+    if (!n) return WH_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int32_t rc;
+    if ((rc = ensure(c, c->d_ids, c->ids_cap, 16 * n))) return rc;
+    uint32_t *d_order = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_order, 4 * n));
+    hipError_t e = hipMemcpyAsync(c->d_ids, ids, 16 * n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        rc = wh_sort_by_testing_id_dev(c, c->d_ids, n, d_order, nullptr, 0, nullptr, nullptr);
+        if (!rc) e = hipMemcpyAsync(order, d_order, 4 * n, hipMemcpyDeviceToHost, c->stream);
+    }
+    hipError_t e2 = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_order);
+    if (rc) return rc;
+    if (e == hipSuccess) e = e2;
+    if (e != hipSuccess) { c->err = std::string("sort: ") + hipGetErrorString(e); return WH_ERR_HIP; }
+    return WH_OK;
+}
+
 int32_t wh_flp_decide_batch(wh_ctx *c, const uint8_t *verifier, uint64_t n, int32_t *decision) {
     if (!c || (n && (!verifier || !decision))) return WH_ERR_PARAM;
     if (n > 0xfffffff0ull) return WH_ERR_PARAM;

@@ -273,10 +273,10 @@ inline PrepareOutcome run_vdaf_prepare(wh_ctx *ctx, const wh_prio3_sizes &sizes,
     for (size_t i = 0; i < n; i++)
         if (status[i]) throw std::runtime_error("report " + std::to_string(i) + " does not decode / verify (status " + std::to_string(status[i]) + ")");
     // sort by testing id (main.rs:93), remembering where each report sits in the batch
-    std::vector<size_t> order(n);
-    for (size_t i = 0; i < n; i++) order[i] = i;
+    std::vector<uint32_t> order(n);
     auto id_of = [&](size_t i) { u128 v; memcpy(&v, ids.data() + 16 * i, 16); return v; };
-    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return id_of(a) < id_of(b); });
+    rc = wh_sort_by_testing_id(ctx, ids.data(), n, order.data());
+    if (rc) throw std::runtime_error(std::string("wh_sort_by_testing_id: ") + wh_last_error(ctx));
     std::vector<ClientProofTag> proof_tags(n);
     for (size_t k = 0; k < n; k++) {
         proof_tags[k].testing_id = id_of(order[k]);
@@ -358,10 +358,10 @@ inline HhOutcome run_hh_expand_and_aggregate(wh_ctx *ctx, const uint8_t verify_k
     if (rc) throw std::runtime_error(std::string("wh_hh_eval_and_check_batch: ") + wh_last_error(ctx));
     for (size_t i = 0; i < n; i++)
         if (status[i]) throw std::runtime_error("key chain " + std::to_string(i) + " does not decode (status " + std::to_string(status[i]) + ")");
-    std::vector<size_t> order(n);
-    for (size_t i = 0; i < n; i++) order[i] = i;
+    std::vector<uint32_t> order(n);
     auto id_of = [&](size_t i) { u128 v; memcpy(&v, ids.data() + 16 * i, 16); return v; };
-    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return id_of(a) < id_of(b); });   // main.rs:266
+    rc = wh_sort_by_testing_id(ctx, ids.data(), n, order.data());                                     // main.rs:266
+    if (rc) throw std::runtime_error(std::string("wh_sort_by_testing_id: ") + wh_last_error(ctx));
     std::vector<HhProofTag> proofs(n);
     for (size_t k = 0; k < n; k++) {
         proofs[k].testing_id = id_of(order[k]);
