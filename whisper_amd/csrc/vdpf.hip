@@ -234,11 +234,7 @@ __device__ __forceinline__ bool hh_prepare(const TabRef &T, const HhTables *__re
     if (!ok) return false;
     // tree: level l has 2^l nodes at seeds[0 .. 2^l); the children of node p go to 2p and 2p+1, in place, from the last
     // 64-parent pass down so that children never land on parents still to be read
-#ifdef HH_EXP_NO_TREE
-    for (uint32_t l = 0; l < 1; l++) {
-#else
     for (uint32_t l = 0; l < depth; l++) {
-#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const B128 cw = ldb128(hdr + L.cw + 18 * l);
         const uint32_t cb0 = hdr[L.cw + 18 * l + 16], cb1 = hdr[L.cw + 18 * l + 17];
@@ -365,11 +361,7 @@ __global__ __launch_bounds__(1024) void k_hh_main(const uint8_t *__restrict__ ke
                 constexpr uint32_t CW = CONSUMERS / 64;
                 // two leaves per pass: 32 table reads in flight per round instead of 16 keeps the LDS queue fed
 #pragma unroll 1
-#ifdef HH_EXP_NO_CONVERT
-                for (uint32_t x = wv; x < 2 * CW; x += 2 * CW) {
-#else
                 for (uint32_t x = wv; x < N; x += 2 * CW) {
-#endif
                     const uint32_t x1 = x + CW < N ? x + CW : x;   // the odd leaf out is computed twice, stored once
                     const uint4 sa = seeds[x], sb = seeds[x1];
                     B128 ca = {{sa.x, sa.y, sa.z, sa.w}}, cb = {{sb.x, sb.y, sb.z, sb.w}};
