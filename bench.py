@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--unique", type=int, default=128, help="with --tiled: distinct clients generated on the CPU")
     ap.add_argument("--tiled", dest="distinct", action="store_false",
                     help="--unique distinct clients sharded on the CPU and tiled, instead of every report from a distinct client sharded on the GPU")
+    ap.add_argument("--in-flight", type=int, default=1, help="contexts the steps alternate between (batches in flight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -160,45 +161,58 @@ def main():
         t_shard = None
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
-    d_tags = torch.zeros(16 * n, dtype=torch.uint8, device=dev)
-    d_ids = torch.zeros(16 * n, dtype=torch.uint8, device=dev)
-    d_status = torch.zeros(n, dtype=torch.int32, device=dev)
     keep = np.ones(n, np.uint8)
     keep[:: 1000] = 0                      # ~0.1 % of the clients flagged by the group test
     d_keep = torch.from_numpy(keep).to(dev)
-    d_agg = torch.zeros(16 * s.output_len, dtype=torch.uint8, device=dev)
-    d_total = torch.zeros(16 * s.output_len, dtype=torch.uint8, device=dev)
+
+    # one lane = one context (stream, workspace) with its own outputs; --in-flight 2 alternates the steps between two
+    # lanes, as a server does that starts on the next batch while the last one is still in its query / aggregation phase
+    class Lane:
+        def __init__(self, v):
+            self.vdaf = v
+            self.ext = torch.cuda.ExternalStream(v.stream, device=dev)
+            self.tags = torch.zeros(16 * n, dtype=torch.uint8, device=dev)
+            self.ids = torch.zeros(16 * n, dtype=torch.uint8, device=dev)
+            self.status = torch.zeros(n, dtype=torch.int32, device=dev)
+            self.agg = torch.zeros(16 * s.output_len, dtype=torch.uint8, device=dev)
+            self.total = torch.zeros(16 * s.output_len, dtype=torch.uint8, device=dev)
+    lanes = [Lane(vdaf)] + [Lane(W.Prio3(params, device=local_rank)) for _ in range(max(1, args.in_flight) - 1)]
+    d_status = lanes[0].status
     torch.cuda.synchronize()
 
-    ext = torch.cuda.ExternalStream(vdaf.stream, device=dev)
-
-    def step():
-        vdaf.prepare_batch_dev(VK, d_blob.data_ptr(), d_off.data_ptr(), n, d_tags.data_ptr(), d_ids.data_ptr(), d_status.data_ptr())
-        vdaf.aggregate_dev(d_keep.data_ptr(), d_agg.data_ptr())
+    def step(i):
+        ln = lanes[i % len(lanes)]
+        ln.vdaf.prepare_batch_dev(VK, d_blob.data_ptr(), d_off.data_ptr(), n, ln.tags.data_ptr(), ln.ids.data_ptr(), ln.status.data_ptr())
+        ln.vdaf.aggregate_dev(d_keep.data_ptr(), ln.agg.data_ptr())
         if world > 1:
             # RCCL all-gather of the raw limbs on the context stream, then the on-GPU mod-p row sum
-            with torch.cuda.stream(ext):
-                rows = all_gather_partials(d_agg)
-            vdaf.sum_rows_dev(rows.data_ptr(), world, s.output_len, None, d_total.data_ptr())
+            with torch.cuda.stream(ln.ext):
+                rows = all_gather_partials(ln.agg)
+            ln.vdaf.sum_rows_dev(rows.data_ptr(), world, s.output_len, None, ln.total.data_ptr())
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        vdaf.synchronize()
+        for ln in lanes:
+            ln.vdaf.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(max(args.warmup, len(lanes) if args.warmup else 0)):
+        step(i)
     barrier()
-    vdaf.set_profiling(True)
-    vdaf.kernel_times(reset=True)
+    for ln in lanes:
+        ln.vdaf.set_profiling(True)
+        ln.vdaf.kernel_times(reset=True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
     barrier()
     elapsed = time.perf_counter() - t0
-    ktimes = vdaf.kernel_times(reset=True)
-    vdaf.set_profiling(False)
+    ktimes = {}
+    for ln in lanes:
+        for k, (ms, cnt) in ln.vdaf.kernel_times(reset=True).items():
+            ktimes[k] = (ktimes.get(k, (0.0, 0))[0] + ms, ktimes.get(k, (0.0, 0))[1] + cnt)
+        ln.vdaf.set_profiling(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -257,7 +271,7 @@ def main():
             "vs_baseline": None, "dtype": "u128 (Field128 mod p) + u64 (Keccak lanes)", "data": "synthetic",
             "config": {"workload": wl["desc"], "reports_per_gpu": n, "distinct_clients": n_distinct, "clients_made_on": "gpu (wh_client_shard_many_gpu)" if args.distinct else "cpu, tiled",
                        "leader_report_bytes": s.leader_report_len, "helper_report_bytes": s.helper_report_len,
-                       "roles": "alternating Leader/Helper", "inputs": "resident in HBM",
+                       "roles": "alternating Leader/Helper", "inputs": "resident in HBM", "batches_in_flight": len(lanes),
                        "parallelism": f"reports sharded over {world} GPU(s); all-gather + mod-p reduce of partial aggregates",
                        "status_nonzero": n_bad_status, "client_gen_s": round(t_gen, 2),
                        "gpu_shard_clients_per_s": round(n / t_shard) if t_shard else None},
@@ -280,7 +294,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    vdaf.close()
+    for ln in lanes:
+        ln.vdaf.close()
     return result
 
 
