@@ -22,7 +22,7 @@ __device__ __forceinline__ void expand_body(const Prio3Dev &P, const Workspace &
     const RepDesc d = W.desc[(sel == 2 ? W.dirty : W.hlist)[slot]];
     // batched report: meas_seed | proof1_seed | jr_blind | proof2_seed; VdafKey: meas_seed | proof_seed | blind
     const uint8_t *seeds = d.seeds;
-    Sponge s;
+    SpongeG s;
     const uint32_t nst = which ? (P.mode ? 1 : 2) : 1;
 #pragma unroll 1
     for (uint32_t t = 0; t < nst; t++) {

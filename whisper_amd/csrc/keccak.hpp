@@ -155,7 +155,29 @@ WH_HD uint64_t ld64(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); 
 WH_HD F128 ld128(const uint8_t *p) { F128 v; __builtin_memcpy(&v, p, 16); return v; }
 WH_HD void st128(uint8_t *p, const F128 &v) { __builtin_memcpy(p, &v, 16); }
 
-struct Sponge {
+// The same through a pointer KNOWN to be in global memory (report bytes, workspace rows).  A generic pointer makes
+// flat_load / flat_store, which count in lgkmcnt as well as vmcnt: the scalar load of a round constant inside the
+// permutation then waits (s_waitcnt lgkmcnt(0)) for every block load put in flight ahead of it and for the stores of the
+// block before.  global_load / global_store count in vmcnt alone.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef uint64_t wh_u64_u1 __attribute__((aligned(1)));
+typedef uint32_t wh_u32x4 __attribute__((ext_vector_type(4)));
+typedef wh_u32x4 wh_u32x4_u1 __attribute__((aligned(1)));
+__device__ __forceinline__ uint64_t ld64g(const uint8_t *p) { return *(const __attribute__((address_space(1))) wh_u64_u1 *)p; }
+__device__ __forceinline__ uint8_t ld8g(const uint8_t *p) { return *(const __attribute__((address_space(1))) uint8_t *)p; }
+__device__ __forceinline__ void st128g(uint8_t *p, const F128 &v) {
+    const wh_u32x4 t = {(uint32_t)v.lo, (uint32_t)(v.lo >> 32), (uint32_t)v.hi, (uint32_t)(v.hi >> 32)};
+    *(__attribute__((address_space(1))) wh_u32x4_u1 *)p = t;
+}
+#else
+WH_HD uint64_t ld64g(const uint8_t *p) { return ld64(p); }
+WH_HD uint8_t ld8g(const uint8_t *p) { return *p; }
+WH_HD void st128g(uint8_t *p, const F128 &v) { st128(p, v); }
+#endif
+
+// G: the byte streams this sponge absorbs and emits live in global memory (device kernels over reports and workspace rows)
+template <bool G>
+struct SpongeT {
     uint64_t st[25];
     uint32_t pos;  // bytes absorbed into (or squeezed from) the current rate block
 
@@ -244,7 +266,7 @@ struct Sponge {
                 uint64_t w[RATE_WORDS];
                 if (pre) {
 #pragma unroll
-                    for (int i = 0; i < (int)RATE_WORDS; i++) w[i] = ld64(p + 8 * i);
+                    for (int i = 0; i < (int)RATE_WORDS; i++) w[i] = G ? ld64g(p + 8 * i) : ld64(p + 8 * i);
                 }
                 keccak_f1600(st);
                 pos = 0;
@@ -262,16 +284,16 @@ struct Sponge {
             }
             if (pos == 0 && len >= SHAKE128_RATE) {
 #pragma unroll
-                for (int i = 0; i < (int)RATE_WORDS; i++) st[i] ^= ld64(p + 8 * i);
+                for (int i = 0; i < (int)RATE_WORDS; i++) st[i] ^= G ? ld64g(p + 8 * i) : ld64(p + 8 * i);
                 p += SHAKE128_RATE; len -= SHAKE128_RATE; pos = SHAKE128_RATE;
             } else if (len >= 8 && pos + 8 <= SHAKE128_RATE) {
-                uint64_t w = ld64(p);
+                uint64_t w = G ? ld64g(p) : ld64(p);
                 uint32_t sh = (pos & 7) * 8, idx = pos >> 3;
                 xor_word(idx, w << sh);
                 if (sh) xor_word(idx + 1, w >> (64 - sh));
                 p += 8; len -= 8; pos += 8;
             } else {
-                xor_word(pos >> 3, (uint64_t)(*p) << (8 * (pos & 7)));
+                xor_word(pos >> 3, (uint64_t)(G ? ld8g(p) : *p) << (8 * (pos & 7)));
                 p++; len--; pos++;
             }
         }
@@ -288,17 +310,20 @@ struct Sponge {
     // Xof::into_seed (xof.rs:127-132): first 16 output bytes
     WH_HD F128 into_seed() { finalize(); return F128{st[0], st[1]}; }
 };
+typedef SpongeT<false> Sponge;
+typedef SpongeT<true> SpongeG;
 
 // Prng::get over a finalized sponge (prng.rs:73-99): consecutive 16-byte chunks of the output
 // stream, little endian, chunks >= p skipped; writes `n` elements (16 B each) at `out`.
 // Two rate blocks hold exactly 21 chunks, so the loop below is the whole stream walk.
 // `bound` is p everywhere except under the test hook wh_*_set_test_sampler_bound.
-WH_HD void xof_emit(Sponge &s, uint8_t *out, uint32_t n, const F128 &bound) {
+template <bool G>
+WH_HD void xof_emit(SpongeT<G> &s, uint8_t *out, uint32_t n, const F128 &bound) {
     uint32_t left = n;
 #define WH_EMIT(lo_, hi_)                                                                      \
     do {                                                                                         \
         uint64_t l_ = (lo_), h_ = (hi_);                                                         \
-        if (left && (h_ < bound.hi || (h_ == bound.hi && l_ < bound.lo))) { st128(out, F128{l_, h_}); out += 16; left--; } \
+        if (left && (h_ < bound.hi || (h_ == bound.hi && l_ < bound.lo))) { if (G) st128g(out, F128{l_, h_}); else st128(out, F128{l_, h_}); out += 16; left--; } \
     } while (0)
     for (;;) {
         // even block: chunks (0,1) .. (18,19); word 20 is the low half of a straddling chunk

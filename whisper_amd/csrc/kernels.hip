@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(256) k_hash(Prio3Dev P, Workspace W, uint32_t 
     const uint8_t *nonce = qr_blind + 16;
     const uint32_t njr = 2 * P.jr_len;
     uint8_t *own = reinterpret_cast<uint8_t *>(&sc->own);
-    Sponge s;
+    SpongeG s;
     F128 sd = f_zero();
     const uint32_t nst = which ? 3 : 6;
 #pragma unroll 1
@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(256) k_hash_base(Prio3Dev P, Workspace W, uint
     RepScal *sc = &W.scal[i];
     const uint8_t *parts = d.base + 1, *nonce = d.tail;
     uint8_t *own = reinterpret_cast<uint8_t *>(&sc->own);
-    Sponge s;
+    SpongeG s;
     F128 sd = f_zero();
 #pragma unroll 1
     for (uint32_t stg = 0; stg < 4; stg++) {
@@ -450,7 +450,7 @@ __global__ void __launch_bounds__(256) k_finish_base(Prio3Dev P, Workspace W, co
     bad = wave_or(bad);
     if (lane == 0) {
         // joint-rand seed over the parts the aggregators sent (prio3.rs:2380-2389)
-        Sponge s;
+        SpongeG s;
         s.init_xof(P.alg_id, DST_JR_SEED, 0ull, 0ull);
         for (uint32_t a = 0; a < na; a++) s.absorb_f(ld128(shares[a] + row + 16ull * vl));
         s.finalize();
@@ -1090,7 +1090,7 @@ __global__ void __launch_bounds__(64) k_test_xof(const uint8_t *seeds, uint32_t 
                            uint32_t binder_len, uint32_t n_elems, uint8_t *out, uint32_t n, F128 bound) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Sponge s;
+    SpongeG s;
     s.init_xof(alg_id, usage, seeds + 16ull * i);
     s.absorb(binder, binder_len);
     s.finalize();

@@ -67,7 +67,7 @@ __device__ __forceinline__ void meas_body(const Prio3Dev &P, const Workspace &W,
     const uint8_t *nonce = P.mode ? d.tail : d.tail + 40 + 32ull * P.verifier_len + 16;
     const F128 bound = P.sampler_bound;
 
-    Sponge s;
+    SpongeG s;
     const uint8_t *key = kind == LANE_SQUEEZE ? d.seeds : d.jr_blind;
     s.init_xof(P.alg_id, kind == LANE_SQUEEZE ? DST_MEAS : DST_JR_PART, ld64(key), ld64(key + 8));
     // the short prefixes never fill a block: [agg_id] for the share stream, [agg_id] . nonce for the part
@@ -93,7 +93,7 @@ __device__ __forceinline__ void meas_body(const Prio3Dev &P, const Workspace &W,
         do {                                                                                     \
             const uint64_t l_ = (lo_), h_ = (hi_);                                               \
             dirty |= even && !(h_ < bound.hi || (h_ == bound.hi && l_ < bound.lo));              \
-            if (even) st128(out, F128{l_, h_});                                                  \
+            if (even) st128g(out, F128{l_, h_});                                                 \
             out += 16;                                                                           \
         } while (0)
 #pragma unroll 1

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void k_shard_encode(ShardDev D, ShardBuf B, ui
 __global__ __launch_bounds__(64) void k_shard_expand_meas(ShardDev D, ShardBuf B, uint32_t n) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
-    Sponge s;
+    SpongeG s;
     s.init_xof(D.alg_id, DST_MEAS, B.rands + 144ull * i);
     s.absorb_byte(1);
     s.finalize();
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64) void k_shard_expand_short(ShardDev D, ShardBuf 
     if (g >= 4 * n) return;
     const uint32_t i = g >> 2, k = g & 3, t = k & 1;
     const uint8_t *r = B.rands + 144ull * i;
-    Sponge s;
+    SpongeG s;
     if (k < 2) {
         s.init_xof(D.alg_id, DST_PROOF, r + 16 + 16 * t);
         s.absorb_byte(1);
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(64) void k_shard_joint_rand(ShardDev D, ShardBuf B,
     F128 part = f_zero();
     if (live) {
         const uint8_t *r = B.rands + 144ull * i;
-        Sponge s;
+        SpongeG s;
         s.init_xof(D.alg_id, DST_JR_PART, r + (agg ? 48 : 64));
         s.absorb_byte((uint8_t)agg);
         s.absorb(B.nonces + 16ull * i, 16);
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64) void k_shard_query_rand(ShardDev D, ShardBuf B,
     if (live) {
         const uint8_t *r = B.rands + 144ull * i;
         const uint8_t *lr = B.lrep + (uint64_t)D.leader_len * i + 49 + 16ull * D.input_len;
-        Sponge s;
+        SpongeG s;
         s.init_xof(D.alg_id, DST_QR_PART, r + (agg ? 112 : 128));
         s.absorb(B.jrf + 32ull * D.jr_len * i, 32 * D.jr_len);
         s.absorb(agg ? B.hp[0] + 16ull * D.proof_len * i : lr, 16 * D.proof_len);
