@@ -212,6 +212,11 @@ int32_t wh_sort_by_testing_id_dev(wh_ctx *ctx, const uint8_t *d_ids, uint64_t n,
                                   uint32_t tag_bytes, uint8_t *d_sorted_ids, uint8_t *d_sorted_tags);
 /* the same permutation for ids in host memory (ids[n][16] in, order[n] out); synchronous */
 int32_t wh_sort_by_testing_id(wh_ctx *ctx, const uint8_t *ids, uint64_t n, uint32_t *order);
+/* replaces: the `if !bad_set.contains(&tag.testing_id)` filter of the merge loops (server-batch-prio3/src/main.rs:108-118,
+ * 173-183; server-hh/src/main.rs:79-103): d_keep[i] = 0 iff the testing id of report i (d_ids[n][16], device, 16-byte aligned)
+ * is one of the n_bad ids the group test returned (bad_ids[n_bad][16], little endian, HOST memory, any order), else 1.
+ * The mask then goes to wh_prio3_aggregate_dev / wh_hh_aggregate_dev. */
+int32_t wh_keep_mask_dev(wh_ctx *ctx, const uint8_t *d_ids, uint64_t n, const uint8_t *bad_ids, uint64_t n_bad, uint8_t *d_keep);
 
 int32_t wh_ctx_synchronize(wh_ctx *ctx);
 

@@ -74,3 +74,31 @@ def test_sort_few_distinct_ids_and_hh_tags():
             ctx.sort_by_testing_id_dev(d_ids.data_ptr(), n, d_order.data_ptr(), d_ids.data_ptr(), 24, None, d_ids.data_ptr())
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("n,n_bad", [(1, 0), (1, 1), (1000, 0), (1000, 17), (125_000, 125), (300_001, 5000)])
+def test_keep_mask_from_bad_ids(n, n_bad):
+    """The merge loops' `!bad_set.contains(testing_id)` (server-batch-prio3/src/main.rs:108-118) as a mask on the GPU."""
+    rng = np.random.default_rng(7 * n + n_bad)
+    ids = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    if n >= 1000:
+        ids[10] = ids[11]                                  # a duplicated id is rejected in both places
+        ids[20, 8:] = ids[21, 8:]                          # equal high halves only: distinct ids
+    as_int = [int.from_bytes(ids[i].tobytes(), "little") for i in range(n)]
+    chosen = rng.choice(n, n_bad, replace=False) if n_bad else np.zeros(0, np.int64)
+    if n >= 1000 and n_bad:
+        chosen[0], chosen[1] = 10, 20
+    bad = [as_int[i] for i in chosen] + ([12345, (1 << 128) - 1] if n_bad else [])     # ids nobody has are ignored
+    rng.shuffle(bad)
+    dev = torch.device("cuda:0")
+    d_ids = torch.from_numpy(ids.copy()).to(dev)
+    d_keep = torch.full((n,), 7, dtype=torch.uint8, device=dev)
+    vdaf = W.Prio3(W.Prio3Params(W.SUMVEC, 2, 5, 3))
+    try:
+        vdaf.keep_mask_dev(d_ids.data_ptr(), n, bad, d_keep.data_ptr())
+        vdaf.synchronize()
+        bad_set = set(bad)
+        want = np.array([0 if v in bad_set else 1 for v in as_int], np.uint8)
+        assert np.array_equal(d_keep.cpu().numpy(), want)
+    finally:
+        vdaf.close()

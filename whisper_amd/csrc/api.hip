@@ -6,6 +6,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <algorithm>
 #include "host_math.hpp"
 #include "aes_host.hpp"
 #include "hh_dev.hpp"
@@ -70,6 +71,7 @@ struct wh_ctx {
     // testing-id sort (sort.hip)
     uint32_t *d_sort_tmp = nullptr; uint64_t sort_tmp_cap = 0;
     uint32_t *d_sort_hist = nullptr; uint64_t sort_hist_cap = 0;
+    uint64_t *d_bad_ids = nullptr; uint64_t bad_ids_cap = 0;
     double k_ms[WH_NUM_KERNELS] = {0};
     uint64_t k_launches[WH_NUM_KERNELS] = {0};
     std::string err;
@@ -274,7 +276,7 @@ void wh_ctx_destroy(wh_ctx *c) {
                     c->d_blob, c->d_offsets, c->d_tags, c->d_ids, c->d_prep, c->W.desc, c->W.scal, c->W.weights, c->W.wlimbs, c->W.pows, c->W.rlc,
                     c->W.hrows, c->W.hlist, c->W.llist, c->W.dirty, c->W.counters,
                     c->d_omega2m, c->d_twist, c->d_hh_tab, c->hh_w.tpc, c->hh_w.proofblk, c->hh_w.supd, c->hh_w.buckg, c->d_hh_dat, c->d_hh_keys, c->d_hh_tags,
-                    c->d_hh_ids, c->d_hh_status, c->d_hh_keep, c->d_hh_acc, c->d_sort_tmp, c->d_sort_hist};
+                    c->d_hh_ids, c->d_hh_status, c->d_hh_keep, c->d_hh_acc, c->d_sort_tmp, c->d_sort_hist, c->d_bad_ids};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
@@ -663,6 +665,27 @@ int32_t wh_sort_by_testing_id_dev(wh_ctx *c, const uint8_t *d_ids, uint64_t n, u
       if (!e && d_sorted_ids) e = launch_sort_gather(d_ids, 16, d_order, (uint32_t)n, d_sorted_ids, c->stream);
       if (!e && d_sorted_tags) e = launch_sort_gather(d_tags, tag_bytes, d_order, (uint32_t)n, d_sorted_tags, c->stream); }
     if (e) { c->err = std::string("sort launch: ") + hipGetErrorString((hipError_t)e); return WH_ERR_HIP; }
+    return WH_OK;
+}
+
+// the filter of the servers' merge loops: keep[i] = !bad_set.contains(testing_id[i])
+int32_t wh_keep_mask_dev(wh_ctx *c, const uint8_t *d_ids, uint64_t n, const uint8_t *bad_ids, uint64_t n_bad, uint8_t *d_keep) {
+    if (!c || (n && (!d_ids || !d_keep)) || (n_bad && !bad_ids)) return WH_ERR_PARAM;
+    if (n > 0xfffffff0ull || n_bad > 0xfffffff0ull) return WH_ERR_PARAM;
+    if (!n) return WH_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    typedef unsigned __int128 u128;
+    std::vector<u128> bad(n_bad);
+    if (n_bad) memcpy(bad.data(), bad_ids, 16 * n_bad);
+    std::sort(bad.begin(), bad.end());
+    int32_t rc;
+    if ((rc = ensure(c, c->d_bad_ids, c->bad_ids_cap, 2 * (n_bad ? n_bad : 1)))) return rc;
+    if (n_bad) {
+        HIPCHK(c, hipMemcpyAsync(c->d_bad_ids, bad.data(), 16 * n_bad, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));         // `bad` is a local
+    }
+    const int e = launch_keep_mask(d_ids, (uint32_t)n, c->d_bad_ids, (uint32_t)n_bad, d_keep, c->stream);
+    if (e) { c->err = std::string("keep mask launch: ") + hipGetErrorString((hipError_t)e); return WH_ERR_HIP; }
     return WH_OK;
 }
 

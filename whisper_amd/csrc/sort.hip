@@ -84,7 +84,28 @@ __global__ __launch_bounds__(256) void k_sort_gather(const uint4 *rows, uint32_t
     out[g] = rows[(uint64_t)order[k] * row_u4 + q];
 }
 
+// keep[i] = 0 iff ids[i] is in the sorted list `bad` (pairs lo, hi; ascending as u128): binary search per report
+__global__ __launch_bounds__(256) void k_keep_mask(const uint8_t *ids, uint32_t n, const uint64_t *bad, uint32_t n_bad, uint8_t *keep) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint4 v = *reinterpret_cast<const uint4 *>(ids + 16ull * i);
+    const uint64_t lo = v.x | ((uint64_t)v.y << 32), hi = v.z | ((uint64_t)v.w << 32);
+    uint32_t a = 0, b = n_bad;                 // first entry >= id
+    while (a < b) {
+        const uint32_t m = (a + b) >> 1;
+        const uint64_t ml = bad[2 * m], mh = bad[2 * m + 1];
+        if (mh < hi || (mh == hi && ml < lo)) a = m + 1; else b = m;
+    }
+    keep[i] = !(a < n_bad && bad[2 * a] == lo && bad[2 * a + 1] == hi);
+}
+
 }  // namespace
+
+int launch_keep_mask(const uint8_t *d_ids, uint32_t n, const uint64_t *d_bad, uint32_t n_bad, uint8_t *d_keep, hipStream_t st) {
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_keep_mask, dim3((n + 255) / 256), dim3(256), 0, st, d_ids, n, d_bad, n_bad, d_keep);
+    return (int)hipGetLastError();
+}
 
 int launch_sort_by_id(const uint8_t *d_ids, uint32_t n, uint32_t *d_order, uint32_t *d_tmp, uint32_t *d_hist, hipStream_t st) {
     if (!n) return 0;

@@ -169,6 +169,11 @@ class HeavyHitters:
         self._chk(lib.wh_sort_by_testing_id_dev(self._ctx, d_ids, n, d_order, d_tags, tag_bytes, d_sorted_ids, d_sorted_tags),
                   "sort_by_testing_id_dev")
 
+    def keep_mask_dev(self, d_ids, n, bad_ids, d_keep):
+        """keep[i] = testing id i not in bad_ids (iterable of ints, the group test's verdict); device buffers as raw pointers."""
+        bad = np.frombuffer(b"".join(int(x).to_bytes(16, "little") for x in bad_ids), np.uint8) if len(bad_ids) else np.zeros(0, np.uint8)
+        self._chk(lib.wh_keep_mask_dev(self._ctx, d_ids, n, bad.ctypes.data if len(bad) else None, len(bad) // 16, d_keep), "keep_mask_dev")
+
     def set_profiling(self, on=True):
         self._chk(lib.wh_ctx_set_profiling(self._ctx, int(on)), "set_profiling")
 
