@@ -102,3 +102,56 @@ def test_keep_mask_from_bad_ids(n, n_bad):
         assert np.array_equal(d_keep.cpu().numpy(), want)
     finally:
         vdaf.close()
+
+
+def test_device_resident_server_flow():
+    """run_vdaf_prepare (server-batch-prio3/src/main.rs:65-125) with everything but the group test on the GPU: prepare,
+    sort by testing id, (host: general_binary_split_test on the sorted tags), keep mask from the bad ids, masked aggregate.
+    Same bad set and aggregate as the host-side flow of test_gpu_parity.py."""
+    from common import VK, make_reports, server_views, blob_of
+    p = W.Prio3Params(W.SUMVEC, 16, 16, 8)
+    n, bad = 3000, {3, 17, 18, 1501, 2999}
+    lr, hr, meas = make_reports(p, n, seed=99)
+    dev = torch.device("cuda:0")
+    vdaf = W.Prio3(p)
+    try:
+        sorted_views, keep_inputs = [], []
+        for reports in server_views(lr, hr, bad):
+            blob, off = blob_of(reports)
+            d_blob = torch.from_numpy(np.concatenate([blob, np.zeros(1, np.uint8)])).to(dev)
+            d_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+            d_tags = torch.zeros(16 * n, dtype=torch.uint8, device=dev)
+            d_ids = torch.zeros(16 * n, dtype=torch.uint8, device=dev)
+            d_status = torch.zeros(n, dtype=torch.int32, device=dev)
+            d_order = torch.zeros(n, dtype=torch.int32, device=dev)
+            d_sids, d_stags = torch.zeros_like(d_ids), torch.zeros_like(d_tags)
+            torch.cuda.synchronize()
+            vdaf.prepare_batch_dev(VK, d_blob.data_ptr(), d_off.data_ptr(), n, d_tags.data_ptr(), d_ids.data_ptr(), d_status.data_ptr())
+            vdaf.sort_by_testing_id_dev(d_ids.data_ptr(), n, d_order.data_ptr(), d_tags.data_ptr(), 16, d_sids.data_ptr(), d_stags.data_ptr())
+            vdaf.synchronize()
+            assert not d_status.cpu().numpy().any()
+            sids, stags = d_sids.cpu().numpy().reshape(n, 16), d_stags.cpu().numpy().reshape(n, 16)
+            proofs = [W.ClientProofTag(int.from_bytes(sids[k].tobytes(), "little"), stags[k].tobytes()) for k in range(n)]
+            assert all(proofs[k].testing_id <= proofs[k + 1].testing_id for k in range(n - 1))
+            sorted_views.append(proofs)
+            keep_inputs.append((d_blob, d_off, d_ids.clone()))
+        bad_a, bad_b, rounds = W.general_binary_split_test(sorted_views[0], sorted_views[1], VK, len(bad), 16)
+        assert bad_a == bad_b and len(bad_a) == len(bad) and rounds > 1
+        aggs = []
+        for (d_blob, d_off, d_ids), bad_ids in zip(keep_inputs, (bad_a, bad_b)):
+            d_tags = torch.zeros(16 * n, dtype=torch.uint8, device=dev)
+            d_ids2 = torch.zeros(16 * n, dtype=torch.uint8, device=dev)
+            d_status = torch.zeros(n, dtype=torch.int32, device=dev)
+            d_keep = torch.zeros(n, dtype=torch.uint8, device=dev)
+            d_agg = torch.zeros(16 * p.sizes.output_len, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            vdaf.prepare_batch_dev(VK, d_blob.data_ptr(), d_off.data_ptr(), n, d_tags.data_ptr(), d_ids2.data_ptr(), d_status.data_ptr())
+            vdaf.keep_mask_dev(d_ids.data_ptr(), n, sorted(bad_ids), d_keep.data_ptr())
+            vdaf.aggregate_dev(d_keep.data_ptr(), d_agg.data_ptr())
+            vdaf.synchronize()
+            keep = d_keep.cpu().numpy()
+            assert set(np.flatnonzero(keep == 0)) == bad
+            aggs.append(d_agg.cpu().numpy().tobytes())
+        assert W.Prio3.unshard(aggs) == [int(sum(int(meas[i][e]) for i in range(n) if i not in bad)) for e in range(16)]
+    finally:
+        vdaf.close()
