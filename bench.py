@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--tiled", dest="distinct", action="store_false",
                     help="--unique distinct clients sharded on the CPU and tiled, instead of every report from a distinct client sharded on the GPU")
     ap.add_argument("--in-flight", type=int, default=1, help="contexts the steps alternate between (batches in flight)")
+    ap.add_argument("--with-sort", action="store_true", help="also sort by testing id and build the keep mask from bad ids inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -176,14 +177,32 @@ def main():
             self.status = torch.zeros(n, dtype=torch.int32, device=dev)
             self.agg = torch.zeros(16 * s.output_len, dtype=torch.uint8, device=dev)
             self.total = torch.zeros(16 * s.output_len, dtype=torch.uint8, device=dev)
+            if args.with_sort:
+                self.order = torch.zeros(n, dtype=torch.int32, device=dev)
+                self.sids, self.stags = torch.zeros_like(self.ids), torch.zeros_like(self.tags)
+                self.keep = torch.zeros(n, dtype=torch.uint8, device=dev)
     lanes = [Lane(vdaf)] + [Lane(W.Prio3(params, device=local_rank)) for _ in range(max(1, args.in_flight) - 1)]
     d_status = lanes[0].status
     torch.cuda.synchronize()
+    bad_ids = []
+    if args.with_sort:
+        # the verdict a group test would return: the testing ids of the clients keep[] drops (from one untimed pass)
+        ln = lanes[0]
+        ln.vdaf.prepare_batch_dev(VK, d_blob.data_ptr(), d_off.data_ptr(), n, ln.tags.data_ptr(), ln.ids.data_ptr(), ln.status.data_ptr())
+        ln.vdaf.synchronize()
+        ids_h = ln.ids.view(n, 16)[torch.from_numpy(np.flatnonzero(keep == 0)).to(dev)].cpu().numpy()
+        bad_ids = [int.from_bytes(r.tobytes(), "little") for r in ids_h]
 
     def step(i):
         ln = lanes[i % len(lanes)]
         ln.vdaf.prepare_batch_dev(VK, d_blob.data_ptr(), d_off.data_ptr(), n, ln.tags.data_ptr(), ln.ids.data_ptr(), ln.status.data_ptr())
-        ln.vdaf.aggregate_dev(d_keep.data_ptr(), ln.agg.data_ptr())
+        if args.with_sort:
+            # the rest of the server's step that can live on the GPU: order for the group test, mask from its verdict
+            ln.vdaf.sort_by_testing_id_dev(ln.ids.data_ptr(), n, ln.order.data_ptr(), ln.tags.data_ptr(), 16, ln.sids.data_ptr(), ln.stags.data_ptr())
+            ln.vdaf.keep_mask_dev(ln.ids.data_ptr(), n, bad_ids, ln.keep.data_ptr())
+            ln.vdaf.aggregate_dev(ln.keep.data_ptr(), ln.agg.data_ptr())
+        else:
+            ln.vdaf.aggregate_dev(d_keep.data_ptr(), ln.agg.data_ptr())
         if world > 1:
             # RCCL all-gather of the raw limbs on the context stream, then the on-GPU mod-p row sum
             with torch.cuda.stream(ln.ext):
@@ -271,7 +290,7 @@ def main():
             "vs_baseline": None, "dtype": "u128 (Field128 mod p) + u64 (Keccak lanes)", "data": "synthetic",
             "config": {"workload": wl["desc"], "reports_per_gpu": n, "distinct_clients": n_distinct, "clients_made_on": "gpu (wh_client_shard_many_gpu)" if args.distinct else "cpu, tiled",
                        "leader_report_bytes": s.leader_report_len, "helper_report_bytes": s.helper_report_len,
-                       "roles": "alternating Leader/Helper", "inputs": "resident in HBM", "batches_in_flight": len(lanes),
+                       "roles": "alternating Leader/Helper", "inputs": "resident in HBM", "batches_in_flight": len(lanes), "sort_and_keep_mask_in_step": bool(args.with_sort),
                        "parallelism": f"reports sharded over {world} GPU(s); all-gather + mod-p reduce of partial aggregates",
                        "status_nonzero": n_bad_status, "client_gen_s": round(t_gen, 2),
                        "gpu_shard_clients_per_s": round(n / t_shard) if t_shard else None},
