@@ -74,6 +74,17 @@ def test_full_size_two_servers(name, cfg, n):
             vdaf.synchronize()
             res.append((d_tags.view(n, 16).cpu().numpy(), d_ids.view(n, 16).cpu().numpy(), d_status.cpu().numpy(), d_agg.cpu().numpy().tobytes()))
         (tags_a, ids_a, st_a, agg_a), (tags_b, ids_b, st_b, agg_b) = res
+        # a second pass over Alice's batch gives the same bytes (no dependence on scheduling or on workspace left-overs)
+        d_tags = torch.zeros(16 * n, dtype=torch.uint8, device=dev)
+        d_ids = torch.zeros(16 * n, dtype=torch.uint8, device=dev)
+        d_status = torch.full((n,), -99, dtype=torch.int32, device=dev)
+        d_agg = torch.zeros(16 * s.output_len, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        vdaf.prepare_batch_dev(VK, blob_a.data_ptr(), off_a.data_ptr(), n, d_tags.data_ptr(), d_ids.data_ptr(), d_status.data_ptr())
+        vdaf.aggregate_dev(d_keep.data_ptr(), d_agg.data_ptr())
+        vdaf.synchronize()
+        assert np.array_equal(d_tags.view(n, 16).cpu().numpy(), tags_a) and np.array_equal(d_ids.view(n, 16).cpu().numpy(), ids_a)
+        assert d_agg.cpu().numpy().tobytes() == agg_a
         assert not st_a.any() and not st_b.any()
         assert np.array_equal(ids_a, ids_b)
         assert len(np.unique(ids_a.view(np.uint64).reshape(n, 2), axis=0)) == n          # distinct clients, distinct testing ids
