@@ -139,3 +139,22 @@ def test_bucket_recover_like_the_reference():
     sk[(idx + 1) % 64] = 50 * hh.bytes_to_bucket(s1, sign)        # the same votes in the wrong bucket are not reported
     assert hh.recover(sk, 49, 3) == {s1}
     assert hh.recover(sk, 50, 3) == set()
+
+
+def test_entry_points_reject_a_null_context_without_touching_a_gpu():
+    """Argument checks come before any HIP call: every batch entry point returns WH_ERR_PARAM (-1) for a null context."""
+    from whisper_amd._lib import lib
+    n = 4
+    buf = np.zeros(4096, np.uint8)
+    p = buf.ctypes.data
+    assert lib.wh_prio3_prepare_batch(None, p, p, p, n, p, p, p) == -1
+    assert lib.wh_prio3_prepare_batch_dev(None, p, p, p, n, p, p, p) == -1
+    assert lib.wh_prio3_aggregate(None, p, p) == -1
+    assert lib.wh_flp_query_batch(None, p, p, p, p, 1, n, p, p) == -1
+    assert lib.wh_flp_prove_batch(None, p, p, p, n, p, p) == -1
+    assert lib.wh_client_shard_many_gpu(None, p, 1, p, p, 0, n, p, p) == -1
+    assert lib.wh_sort_by_testing_id_dev(None, p, n, p, None, 0, None, None) == -1
+    assert lib.wh_sort_by_testing_id(None, p, n, p) == -1
+    assert lib.wh_keep_mask_dev(None, p, n, p, 1, p) == -1
+    assert lib.wh_hh_eval_and_check_batch(None, p, p, 64, n, 9, p, p, p) == -1
+    assert lib.wh_hh_aggregate(None, p, p) == -1
