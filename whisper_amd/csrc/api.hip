@@ -658,7 +658,7 @@ int32_t wh_sort_by_testing_id_dev(wh_ctx *c, const uint8_t *d_ids, uint64_t n, u
     HIPCHK(c, hipSetDevice(c->device));
     int32_t rc;
     if ((rc = ensure(c, c->d_sort_tmp, c->sort_tmp_cap, n))) return rc;
-    if ((rc = ensure(c, c->d_sort_hist, c->sort_hist_cap, 256 * sort_blocks(n)))) return rc;
+    if ((rc = ensure(c, c->d_sort_hist, c->sort_hist_cap, 256 * sort_blocks(n) + 256))) return rc;
     int e;
     { KTimer t_(c, WH_K_SORT);
       e = launch_sort_by_id(d_ids, (uint32_t)n, d_order, c->d_sort_tmp, c->d_sort_hist, c->stream);

@@ -26,30 +26,52 @@ __global__ __launch_bounds__(64) void k_sort_hist(const uint8_t *ids, const uint
     for (uint32_t d = lane; d < 256; d += 64) hist[(uint64_t)d * nblk + blk] = cnt[d];
 }
 
-// exclusive scan of the whole table by one workgroup
-__global__ __launch_bounds__(1024) void k_sort_scan(uint32_t *hist, uint32_t total) {
+// one workgroup per bin: exclusive scan of the bin's row of tile counts in place (coalesced, 1 024 tiles at a time) and the
+// bin's total; the scatter turns the 256 totals into bin bases itself
+__global__ __launch_bounds__(1024) void k_sort_scan(uint32_t *hist, uint32_t nblk, uint32_t *totals) {
     __shared__ uint32_t part[1024];
-    const uint32_t t = threadIdx.x, chunk = (total + 1023) / 1024;
-    const uint32_t lo = t * chunk < total ? t * chunk : total, hi = lo + chunk < total ? lo + chunk : total;
-    uint32_t s = 0;
-    for (uint32_t i = lo; i < hi; i++) s += hist[i];
-    part[t] = s;
+    __shared__ uint32_t carry_s;
+    const uint32_t t = threadIdx.x;
+    uint32_t *row = hist + (uint64_t)blockIdx.x * nblk;
+    if (t == 0) carry_s = 0;
     __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {      // Hillis-Steele inclusive scan of the partial sums
-        const uint32_t v = t >= off ? part[t - off] : 0;
+    for (uint32_t base = 0; base < nblk; base += 1024) {
+        const uint32_t i = base + t;
+        const uint32_t v = i < nblk ? row[i] : 0;
+        part[t] = v;
         __syncthreads();
-        part[t] += v;
+        for (uint32_t off = 1; off < 1024; off <<= 1) {      // Hillis-Steele inclusive scan
+            const uint32_t u = t >= off ? part[t - off] : 0;
+            __syncthreads();
+            part[t] += u;
+            __syncthreads();
+        }
+        const uint32_t carry = carry_s;
+        if (i < nblk) row[i] = carry + part[t] - v;
+        __syncthreads();
+        if (t == 1023) carry_s = carry + part[1023];
         __syncthreads();
     }
-    uint32_t run = part[t] - s;
-    for (uint32_t i = lo; i < hi; i++) { const uint32_t v = hist[i]; hist[i] = run; run += v; }
+    if (t == 0) totals[blockIdx.x] = carry_s;
 }
 
 __global__ __launch_bounds__(64) void k_sort_scatter(const uint8_t *ids, const uint32_t *in, uint32_t *out, uint32_t n, uint32_t pass,
-                                                     uint32_t nblk, const uint32_t *hist) {
+                                                     uint32_t nblk, const uint32_t *hist, const uint32_t *totals) {
     __shared__ uint32_t base[256];
     const uint32_t lane = threadIdx.x, blk = blockIdx.x;
-    for (uint32_t d = lane; d < 256; d += 64) base[d] = hist[(uint64_t)d * nblk + blk];
+    {   // bin bases = exclusive scan of the 256 totals: four per lane, then across the wavefront
+        const uint32_t t0 = totals[4 * lane], t1 = totals[4 * lane + 1], t2 = totals[4 * lane + 2], t3 = totals[4 * lane + 3];
+        uint32_t incl = t0 + t1 + t2 + t3;
+        for (uint32_t off = 1; off < 64; off <<= 1) {
+            const uint32_t u = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += u;
+        }
+        const uint32_t ex = incl - (t0 + t1 + t2 + t3);
+        base[4 * lane] = ex + hist[(uint64_t)(4 * lane) * nblk + blk];
+        base[4 * lane + 1] = ex + t0 + hist[(uint64_t)(4 * lane + 1) * nblk + blk];
+        base[4 * lane + 2] = ex + t0 + t1 + hist[(uint64_t)(4 * lane + 2) * nblk + blk];
+        base[4 * lane + 3] = ex + t0 + t1 + t2 + hist[(uint64_t)(4 * lane + 3) * nblk + blk];
+    }
     __syncthreads();
     const uint64_t lt = (1ull << lane) - 1;
     for (uint32_t it = 0; it < SORT_TILE / 64; it++) {
@@ -115,8 +137,8 @@ int launch_sort_by_id(const uint8_t *d_ids, uint32_t n, uint32_t *d_order, uint3
     uint32_t *out = d_tmp;
     for (uint32_t pass = 0; pass < 16; pass++) {
         hipLaunchKernelGGL(k_sort_hist, dim3(nblk), dim3(64), 0, st, d_ids, in, n, pass, nblk, d_hist);
-        hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, st, d_hist, 256 * nblk);
-        hipLaunchKernelGGL(k_sort_scatter, dim3(nblk), dim3(64), 0, st, d_ids, in, out, n, pass, nblk, d_hist);
+        hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(1024), 0, st, d_hist, nblk, d_hist + 256ull * nblk);
+        hipLaunchKernelGGL(k_sort_scatter, dim3(nblk), dim3(64), 0, st, d_ids, in, out, n, pass, nblk, d_hist, d_hist + 256ull * nblk);
         in = out;
         out = out == d_tmp ? d_order : d_tmp;
     }
