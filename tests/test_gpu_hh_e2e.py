@@ -107,3 +107,57 @@ def test_heavy_hitters_end_to_end(streaming):
     assert {pop[0], pop[1]} <= recovered_gpu                     # the true heavy hitters are found
     assert recovered_gpu <= set(pop)                             # and nothing that no client sent
     ha.close(); hb.close()
+
+
+def test_heavy_hitters_device_resident_repetition():
+    """One repetition of batch_collect_and_aggregate_per_run (server-hh/src/main.rs:255-282) with everything but the group
+    test on the GPU: expansion, sort by testing id (64-byte proof strings gathered in sorted order), keep mask from the
+    rejected ids, masked sketch sum.  Same rejected clients and sketches as the host-buffer flow above."""
+    import torch
+    from whisper_amd import hh
+    from whisper_amd.grouptest import ClientProofTag, general_binary_split_test
+    A, B, strings, bad, pop = _clients()
+    nb, n, r = 1 << DEPTH, N_CLIENTS, 1
+    dev = torch.device("cuda:0")
+    servers = [hh.HeavyHitters(nb), hh.HeavyHitters(nb)]
+    try:
+        state, views = [], []
+        for h, keys in zip(servers, (A[r], B[r])):
+            d_keys = torch.from_numpy(np.ascontiguousarray(keys)).to(dev)
+            d_tags = torch.zeros(64 * n, dtype=torch.uint8, device=dev)
+            d_ids = torch.zeros(16 * n, dtype=torch.uint8, device=dev)
+            d_status = torch.zeros(n, dtype=torch.int32, device=dev)
+            d_order = torch.zeros(n, dtype=torch.int32, device=dev)
+            d_sids, d_stags = torch.zeros_like(d_ids), torch.zeros_like(d_tags)
+            torch.cuda.synchronize()
+            h.eval_and_check_dev(VK, d_keys.data_ptr(), keys.shape[1], n, None, d_tags.data_ptr(), d_ids.data_ptr(), d_status.data_ptr())
+            h.sort_by_testing_id_dev(d_ids.data_ptr(), n, d_order.data_ptr(), d_tags.data_ptr(), 64, d_sids.data_ptr(), d_stags.data_ptr())
+            h.synchronize()
+            assert not d_status.cpu().numpy().any()
+            sids, stags = d_sids.cpu().numpy().reshape(n, 16), d_stags.cpu().numpy().reshape(n, 64)
+            views.append([ClientProofTag(int.from_bytes(sids[k].tobytes(), "little"), stags[k].tobytes()) for k in range(n)])
+            state.append((d_ids, d_keys))
+        bad_a, bad_b, _ = general_binary_split_test(views[0], views[1], VK, len(bad), tag_size=32)
+        assert bad_a == bad_b and len(bad_a) == len(bad)
+        sketches = []
+        for h, (d_ids, _), keys in zip(servers, state, (A[r], B[r])):
+            d_keep = torch.zeros(n, dtype=torch.uint8, device=dev)
+            d_acc = torch.zeros(nb * 258, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            h.keep_mask_dev(d_ids.data_ptr(), n, sorted(bad_a), d_keep.data_ptr())
+            h.aggregate_hhs_dev(d_keep.data_ptr(), d_acc.data_ptr())
+            h.synchronize()
+            keep = d_keep.cpu().numpy()
+            assert set(int(i) for i in np.flatnonzero(keep == 0)) == bad
+            sketches.append(d_acc.cpu().numpy().view(np.uint32).reshape(nb, 258))
+            dat, _, _, _ = o.hh_eval_and_check_batch(DEPTH, VK, keys, nthreads=4)
+            assert (sketches[-1] == o.hh_bucket_sum_u32(dat, keep)).all()
+        want = np.zeros((nb, 258), np.uint32)
+        for c in range(N_CLIENTS):
+            if c not in bad:
+                sign, idx = hh.get_sign_and_bkt(strings[c], nb, r)
+                want[idx] += hh.bytes_to_bucket(strings[c], sign)
+        assert (sketches[0] + sketches[1] == want).all()
+    finally:
+        for h in servers:
+            h.close()
