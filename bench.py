@@ -247,6 +247,9 @@ def main():
     for k, (ms, cnt) in ktimes.items():
         if cnt:
             kernels[k] = {"ms_per_step": ms / args.steps, "launches_per_step": cnt / args.steps}
+            if k in per and ms > 0:      # algorithmic bytes of the step over the kernel's time: its own HBM roofline figure
+                kernels[k]["alg_gb_per_s"] = per[k] / (ms / args.steps * 1e-3) / 1e9
+                kernels[k]["hbm_frac"] = kernels[k]["alg_gb_per_s"] / HBM_PEAK_GBS
     # expand and hash have a launch on the side stream whose event time includes waiting for free slots
     dom = max((k for k in kernels if k in per and k not in ("expand",)), key=lambda k: kernels[k]["ms_per_step"])
     launches = kernels[dom]["launches_per_step"]
