@@ -29,7 +29,7 @@ def run(ctx, ids, tags):
     return d_order.cpu().numpy().view(np.uint32)[:n], d_sids.cpu().numpy(), d_stags.cpu().numpy()
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 1023, 1024, 1025, 5000, 125_000, 1_000_003])
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 1023, 1024, 1025, 5000, 125_000, 1_000_003, 1_300_000])   # the last: more than 1 024 tiles per bin row
 def test_sort_matches_stable_host_sort(n):
     rng = np.random.default_rng(n + 1)
     ids = rng.integers(0, 256, (n, 16), dtype=np.uint8)
