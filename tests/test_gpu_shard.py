@@ -80,3 +80,35 @@ def test_gpu_shard_rejects_out_of_range_measurement():
         assert lr0.shape[0] == 0 and hr0.shape[0] == 0
     finally:
         vdaf.close()
+
+
+def test_gpu_shard_random_shapes():
+    """Seeded random circuit shapes (ragged last chunks, chunk > input, one-call circuits): the GPU sharder, the CPU client
+    and the verifier agree on every one."""
+    rng = np.random.default_rng(20240807)
+    shapes = []
+    for _ in range(14):
+        bits, ln = int(rng.integers(1, 17)), int(rng.integers(1, 41))
+        shapes.append((W.SUMVEC, bits, ln, int(rng.integers(1, bits * ln + 3))))
+    for _ in range(8):
+        ln = int(rng.integers(2, 61))
+        shapes.append((W.HISTOGRAM, 0, ln, int(rng.integers(1, ln + 3))))
+    for bits in (1, 2, 31, 33, 63):
+        shapes.append((W.AVERAGE, bits, 0, 0))
+    vk = bytes(det(b"rvk", 16))
+    for k, (circ, bits, ln, ch) in enumerate(shapes):
+        p = W.Prio3Params(circ, bits, ln, ch)
+        n = 3
+        meas = measurements(circ, bits, ln, n, b"rs%d" % k)
+        nonces = np.frombuffer(det(b"rn%d" % k, 16 * n), np.uint8).reshape(n, 16)
+        rands = np.frombuffer(det(b"rr%d" % k, 144 * n), np.uint8).reshape(n, 144)
+        vdaf = W.Prio3(p)
+        try:
+            lr, hr = vdaf.shard_batched_many(meas, nonces, rands, 1000 * k)
+            lr_cpu, hr_cpu = W.shard_batched_many(p, meas, nonces, rands, 1000 * k, nthreads=2)
+            assert np.array_equal(lr, lr_cpu) and np.array_equal(hr, hr_cpu), (circ, bits, ln, ch)
+            res = [vdaf.prepare_encoded_keys(vk, [r.tobytes() for r in rep]) for rep in (lr, hr)]
+            assert not res[0][2].any() and not res[1][2].any(), (circ, bits, ln, ch)
+            assert np.array_equal(res[0][0], res[1][0]), (circ, bits, ln, ch)
+        finally:
+            vdaf.close()
