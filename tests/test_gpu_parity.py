@@ -389,3 +389,36 @@ def test_sum_rows_and_hh_bucket_sum():
             assert np.array_equal(d_acc.cpu().numpy().view(np.uint32), O.hh_bucket_sum_u32(buckets, keep))
     finally:
         vdaf.close()
+
+
+def test_prepare_matches_oracle_on_random_shapes():
+    """Seeded random circuit shapes (ragged last chunks, chunk > input_len, odd bit widths): tags, testing ids, status, out
+    shares and the masked aggregate of both servers against the oracle, bit for bit, with one tampered client per shape."""
+    rng = np.random.default_rng(7020240807)
+    shapes = []
+    for _ in range(12):
+        bits, ln = int(rng.integers(1, 17)), int(rng.integers(1, 41))
+        shapes.append((W.SUMVEC, bits, ln, int(rng.integers(1, bits * ln + 3))))
+    for _ in range(6):
+        ln = int(rng.integers(2, 61))
+        shapes.append((W.HISTOGRAM, 0, ln, int(rng.integers(1, ln + 3))))
+    for bits in (1, 7, 33, 64):
+        shapes.append((W.AVERAGE, bits, 0, 0))
+    for k, (circ, bits, ln, ch) in enumerate(shapes):
+        p = W.Prio3Params(circ, bits, ln, ch)
+        op = O.params(circ, bits, ln, ch)
+        n = 6
+        lr, hr, _ = make_reports(p, n, seed=500 + k, nthreads=2)
+        keep = np.ones(n, np.uint8)
+        keep[2] = 0
+        vdaf = W.Prio3(p)
+        try:
+            for reports in server_views(lr, hr, {2}):
+                tags, ids, status = vdaf.prepare_encoded_keys(VK, reports)
+                o_tags, o_ids, o_status, o_outs = oracle_batch(op, reports)
+                assert np.array_equal(status, o_status) and not status.any(), (circ, bits, ln, ch)
+                assert np.array_equal(tags, o_tags) and np.array_equal(ids, o_ids), (circ, bits, ln, ch)
+                assert np.array_equal(np.asarray(vdaf.out_shares()).reshape(n, -1), np.asarray(o_outs).reshape(n, -1)), (circ, bits, ln, ch)
+                assert np.array_equal(vdaf.aggregate(keep), O.prio3_aggregate(o_outs, p.sizes.output_len, keep)), (circ, bits, ln, ch)
+        finally:
+            vdaf.close()
