@@ -422,3 +422,52 @@ def test_prepare_matches_oracle_on_random_shapes():
                 assert np.array_equal(vdaf.aggregate(keep), O.prio3_aggregate(o_outs, p.sizes.output_len, keep)), (circ, bits, ln, ch)
         finally:
             vdaf.close()
+
+
+@pytest.mark.parametrize("cfg", [(W.SUMVEC, 16, 16, 8), (W.SUMVEC, 3, 11, 7), (W.HISTOGRAM, 0, 11, 3), (W.AVERAGE, 9, 0, 0)],
+                         ids=["sumvec_16_16_8", "sumvec_ragged", "histogram_11_3", "average_9"])
+def test_mutated_reports_differential_fuzz(cfg):
+    """Seeded mutations of valid reports -- byte flips anywhere, truncations, extensions, elements overwritten with values
+    at and above p, the all-ones word, length prefixes off by one -- through the GPU and the oracle: same status for every
+    report, and the same tag, testing id and out share wherever the report still decodes."""
+    circ, bits, ln, ch = cfg
+    p = W.Prio3Params(circ, bits, ln, ch)
+    op = O.params(circ, bits, ln, ch)
+    n = 48
+    lr, hr, _ = make_reports(p, n, seed=4242 + ln, nthreads=4)
+    alice, bob = server_views(lr, hr)
+    rng = np.random.default_rng(99 + bits + ln)
+    special = [O.P128, O.P128 - 1, O.P128 + 1, (1 << 128) - 1, (0xffffffff << 96), 0]
+    vdaf = W.Prio3(p)
+    try:
+        for reports in (alice, bob):
+            mutated = []
+            for r in reports:
+                x = bytearray(r)
+                kind = int(rng.integers(0, 7))
+                if kind == 0:                                   # one byte flipped anywhere
+                    x[int(rng.integers(0, len(x)))] ^= 1 << int(rng.integers(0, 8))
+                elif kind == 1:                                 # truncated
+                    x = x[: int(rng.integers(0, len(x)))]
+                elif kind == 2:                                 # extended (trailing bytes are ignored)
+                    x += bytes(rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8))
+                elif kind == 3 and len(x) >= 49 + 16:           # a 16-byte window overwritten with a boundary value
+                    off = 49 + 16 * int(rng.integers(0, (len(x) - 49) // 16))
+                    x[off:off + 16] = special[int(rng.integers(0, len(special)))].to_bytes(16, "little")
+                elif kind == 4:                                 # a header byte replaced
+                    x[int(rng.integers(0, 49))] = int(rng.integers(0, 256))
+                elif kind == 5:                                 # several byte flips in the tail (query-rand parts, lengths, public proofs)
+                    for _ in range(3):
+                        x[len(x) - 1 - int(rng.integers(0, min(len(x), 200)))] ^= 0x80
+                mutated.append(bytes(x))
+            tags, ids, status = vdaf.prepare_encoded_keys(VK, mutated)
+            outs = vdaf.out_shares()
+            o_tags, o_ids, o_status, o_outs = oracle_batch(op, mutated)
+            assert np.array_equal(status, o_status), (list(status), list(o_status))
+            ok = status == 0
+            assert ok.any() and (~ok).any()
+            assert np.array_equal(tags[ok], o_tags[ok]) and np.array_equal(ids[ok], o_ids[ok])
+            assert np.array_equal(np.asarray(outs)[ok], np.asarray(o_outs)[ok])
+            assert np.array_equal(vdaf.aggregate(None), O.prio3_aggregate(o_outs, p.output_len, ok.astype(np.uint8)))
+    finally:
+        vdaf.close()
