@@ -202,3 +202,35 @@ def test_many_key_chains_per_cu_and_mixed_validity():
     tags, ids, status, dat = _check_against_oracle(h, vk, keys, depth)
     assert set(np.nonzero(status)[0]) == set(int(i) for i in broken)
     h.close()
+
+
+@pytest.mark.parametrize("depth", [1, 4, 9])
+def test_mutated_key_chains_differential_fuzz(depth):
+    """Seeded mutations of valid key chains -- a byte flipped anywhere (seeds, correction words, control bits, bincode
+    lengths, bool bytes of the support keys), windows overwritten with 0x00 / 0xff -- through the GPU and the oracle: the
+    same status for every key chain and the same proof string, testing id and bucket vectors, bit for bit."""
+    from whisper_amd import hh
+    vk = bytes(range(60, 76))
+    n = 40
+    A, B, _, _ = _make(depth, n, seed=900 + depth)
+    rng = np.random.default_rng(31 * depth)
+    ln = A.shape[1]
+    h = hh.HeavyHitters(1 << depth)
+    try:
+        for keys in (A, B):
+            m = keys.copy()
+            for i in range(n):
+                kind = int(rng.integers(0, 5))
+                if kind == 0:
+                    m[i, int(rng.integers(0, ln))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+                elif kind == 1:                               # in the header of the main key: key id, root seed, lengths
+                    m[i, int(rng.integers(16, 49))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+                elif kind == 2:
+                    off = int(rng.integers(0, ln - 8))
+                    m[i, off:off + 8] = 0xff if rng.integers(0, 2) else 0
+                elif kind == 3:                               # inside the support keys
+                    m[i, int(rng.integers(ln - 257 * 111, ln))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+            tags, ids, status, dat = _check_against_oracle(h, vk, m, depth)
+            assert (status == 0).any()
+    finally:
+        h.close()
