@@ -131,3 +131,51 @@ def test_prepare_init_matches_oracle(name, cfg, na, n):
         assert vdaf.aggregate(keep).tobytes() == O.prio3_aggregate(vdaf.out_shares()[1:], p.output_len).tobytes()
     finally:
         vdaf.close()
+
+
+@pytest.mark.parametrize("cfg,na", [((W.SUMVEC, 8, 10, 9), 2), ((W.HISTOGRAM, 0, 11, 3), 3), ((W.AVERAGE, 16, 0, 0), 2)],
+                         ids=["sumvec_2", "histogram_3", "sum_2"])
+def test_prepare_init_mutated_keys_differential_fuzz(cfg, na):
+    """Seeded in-place mutations of valid VdafKeys (byte flips, 16-byte windows set to p - 1, p, p + 1, all ones) through
+    the GPU and the oracle's prepare_init: the same status, and the same prepare share and out share where it is zero."""
+    circ, bits, ln, ch = cfg
+    p = W.Prio3Params(circ, bits, ln, ch, na)
+    op = O.params(circ, bits, ln, ch, na)
+    vk = bytes(det(b"fuzzvk", 16))
+    rng = np.random.default_rng(5 + na + ln)
+    special = [O.P128, O.P128 - 1, O.P128 + 1, (1 << 128) - 1, 0]
+    n = 40
+    vdaf = W.Prio3(p)
+    try:
+        for agg_id in range(na):
+            keys = []
+            for i in range(n):
+                nonce = bytes(det(b"fn%d" % i, 16))
+                rand = bytes(det(b"fr%d" % i, O.prio3_rand_size(op)))
+                ps, ish = O.prio3_shard(op, measurement_for(circ, bits, ln, i), nonce, rand)
+                x = bytearray(W.Prio3.encode_vdaf_key(agg_id, ps, ish[agg_id], nonce))
+                kind = int(rng.integers(0, 4))
+                if kind == 0:
+                    x[int(rng.integers(1, len(x)))] ^= 1 << int(rng.integers(0, 8))
+                elif kind == 1:
+                    off = 1 + 16 * int(rng.integers(0, (len(x) - 1) // 16))
+                    x[off:off + 16] = special[int(rng.integers(0, len(special)))].to_bytes(16, "little")
+                elif kind == 2:
+                    for _ in range(4):
+                        x[int(rng.integers(1, len(x)))] = int(rng.integers(0, 256))
+                keys.append(bytes(x))
+            prep, status = vdaf.prepare_init_encoded_keys(vk, keys)
+            outs = vdaf.out_shares()
+            n_ok = 0
+            for j, k in enumerate(keys):
+                ps, rest = k[1:1 + 16 * na], k[1 + 16 * na:]
+                rc, want_prep, want_out = O.prio3_prepare_init(op, vk, agg_id, rest[-16:], ps, rest[:-16])
+                assert status[j] == rc, (agg_id, j, status[j], rc)
+                if rc == 0:
+                    n_ok += 1
+                    assert prep[j].tobytes() == want_prep and outs[j].tobytes() == want_out, (agg_id, j)
+                else:
+                    assert not prep[j].any() and not outs[j].any()
+            assert n_ok
+    finally:
+        vdaf.close()
