@@ -210,6 +210,16 @@ int32_t wh_hh_aggregate_dev(wh_ctx *ctx, const uint8_t *d_keep, uint32_t *d_acc,
  * stream. */
 int32_t wh_sort_by_testing_id_dev(wh_ctx *ctx, const uint8_t *d_ids, uint64_t n, uint32_t *d_order, const uint8_t *d_tags,
                                   uint32_t tag_bytes, uint8_t *d_sorted_ids, uint8_t *d_sorted_tags);
+/* No counterpart in the reference: wh_sort_by_testing_id_dev for callers that cannot allocate -- code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  Same arguments, same results, asynchronous on the context
+ * stream, but the sort's scratch (second permutation buffer + count table, 5.0 MiB) is a file-scope __device__ array that
+ * every GPU the library runs on holds until the process ends, so the call never allocates or frees anything.
+ * n <= WH_SORT_NOALLOC_MAX_N (2^20), larger batches: WH_ERR_PARAM.  All calls on one GPU share that array: calls that
+ * overlap in time on the same GPU (two contexts, two threads) race; calls on one context stream are ordered and safe. */
+#define WH_SORT_NOALLOC_MAX_N (1u << 20)
+int32_t wh_sort_by_testing_id_noalloc_dev(wh_ctx *ctx, const uint8_t *d_ids, uint64_t n, uint32_t *d_order,
+                                          const uint8_t *d_tags, uint32_t tag_bytes, uint8_t *d_sorted_ids,
+                                          uint8_t *d_sorted_tags);
 /* the same permutation for ids in host memory (ids[n][16] in, order[n] out); synchronous */
 int32_t wh_sort_by_testing_id(wh_ctx *ctx, const uint8_t *ids, uint64_t n, uint32_t *order);
 /* replaces: the `if !bad_set.contains(&tag.testing_id)` filter of the merge loops (server-batch-prio3/src/main.rs:108-118,

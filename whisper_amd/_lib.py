@@ -43,6 +43,7 @@ EXPORTS = [
     "wh_test_f64_op", "wh_flp_query_batch", "wh_flp_decide_batch", "wh_flp_encode", "wh_flp_prove", "wh_hh_bucket_accumulate_u32_dev", "wh_prio3_prepare_init_batch_dev", "wh_prio3_prepare_init_batch", "wh_prio3_prepare_finish_batch",
     "wh_hh_key_chain_len", "wh_hh_ctx_create", "wh_hh_eval_and_check_batch_dev", "wh_hh_eval_and_check_batch", "wh_hh_buckets",
     "wh_hh_aggregate", "wh_hh_aggregate_dev", "wh_hh_gen_key_chain", "wh_flp_prove_batch", "wh_client_shard_many_gpu", "wh_sort_by_testing_id_dev", "wh_sort_by_testing_id", "wh_keep_mask_dev",
+    "wh_sort_by_testing_id_noalloc_dev",
 ]
 
 vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32
@@ -84,6 +85,7 @@ lib.wh_flp_prove_batch.argtypes = [vp, vp, vp, vp, u64, vp, vp]
 lib.wh_client_shard_many_gpu.argtypes = [vp, vp, u32, vp, vp, u64, u64, vp, vp]
 lib.wh_sort_by_testing_id_dev.argtypes = [vp, vp, u64, vp, vp, u32, vp, vp]
 lib.wh_sort_by_testing_id.argtypes = [vp, vp, u64, vp]
+lib.wh_sort_by_testing_id_noalloc_dev.argtypes = [vp, vp, u64, vp, vp, u32, vp, vp]
 lib.wh_keep_mask_dev.argtypes = [vp, vp, u64, vp, u64, vp]
 lib.wh_hh_key_chain_len.argtypes = [u32]
 lib.wh_hh_ctx_create.argtypes = [i32, C.POINTER(vp)]

@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <mutex>
 #include "host_math.hpp"
 #include "aes_host.hpp"
 #include "hh_dev.hpp"
@@ -16,6 +17,14 @@
 #include "kernels.hip"
 
 using namespace wh;
+
+// Scratch of wh_sort_by_testing_id_noalloc_dev, the one entry point that allocates nothing: the second permutation
+// buffer (SORT_NOALLOC_MAX_N words) followed by the count table of the largest sort (256 bins x tiles, then 256 bin
+// totals).  In host code the name is only a handle: the address on a device comes from hipGetSymbolAddress, once per
+// device (scratch_of_device below), and every use goes through that pointer.
+constexpr uint64_t SORT_NOALLOC_MAX_N = 1ull << 20;
+constexpr uint64_t SORT_NOALLOC_HIST_WORDS = 256 * (SORT_NOALLOC_MAX_N / SORT_TILE) + 256;
+static __device__ __align__(256) uint32_t scratch[SORT_NOALLOC_MAX_N + SORT_NOALLOC_HIST_WORDS];
 
 namespace wh {
 void launch_expand(const Prio3Dev &P, const Workspace &W, uint32_t npad, uint32_t sel, hipStream_t stream);
@@ -72,6 +81,7 @@ struct wh_ctx {
     uint32_t *d_sort_tmp = nullptr; uint64_t sort_tmp_cap = 0;
     uint32_t *d_sort_hist = nullptr; uint64_t sort_hist_cap = 0;
     uint64_t *d_bad_ids = nullptr; uint64_t bad_ids_cap = 0;
+    uint32_t *d_scratch = nullptr;      // this device's copy of the file-scope `scratch` array (not owned)
     double k_ms[WH_NUM_KERNELS] = {0};
     uint64_t k_launches[WH_NUM_KERNELS] = {0};
     std::string err;
@@ -87,6 +97,24 @@ namespace {
             return WH_ERR_HIP;                                                                    \
         }                                                                                         \
     } while (0)
+
+// Address of the file-scope `scratch` array on the current device.  Every GPU holds its own copy at its own address, so
+// the look-up is made once per device, with that device current, and kept.
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mu;
+uint32_t *g_scratch_ptr[MAX_DEVICES] = {nullptr};
+int32_t scratch_of_device(wh_ctx *c) {
+    if (c->device < 0 || c->device >= MAX_DEVICES) { c->err = "device index beyond the scratch table"; return WH_ERR_NO_DEVICE; }
+    std::lock_guard<std::mutex> g(g_scratch_mu);
+    if (!g_scratch_ptr[c->device]) {
+        void *p = nullptr;
+        HIPCHK(c, hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) { c->err = "hipGetSymbolAddress(scratch) returned a null address"; return WH_ERR_HIP; }
+        g_scratch_ptr[c->device] = static_cast<uint32_t *>(p);
+    }
+    c->d_scratch = g_scratch_ptr[c->device];
+    return WH_OK;
+}
 
 hipEvent_t ev_get(wh_ctx *c) {
     if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
@@ -236,6 +264,8 @@ int32_t wh_ctx_create(int32_t device_id, const wh_prio3_params *params, wh_ctx *
     if (hipStreamCreate(&c->stream2) != hipSuccess) return fail(WH_ERR_HIP);
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(WH_ERR_HIP);
     if (hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) return fail(WH_ERR_HIP);
+    c->err.reserve(256);                 // later error texts need no host allocation either
+    if ((rc = scratch_of_device(c))) return fail(rc);
 
     // constant tables: w^j and s_i = sum_{j=1..calls} w^(ij)
     std::vector<F128> omega(z.m), stab(z.gpoly_len);
@@ -665,6 +695,27 @@ int32_t wh_sort_by_testing_id_dev(wh_ctx *c, const uint8_t *d_ids, uint64_t n, u
       if (!e && d_sorted_ids) e = launch_sort_gather(d_ids, 16, d_order, (uint32_t)n, d_sorted_ids, c->stream);
       if (!e && d_sorted_tags) e = launch_sort_gather(d_tags, tag_bytes, d_order, (uint32_t)n, d_sorted_tags, c->stream); }
     if (e) { c->err = std::string("sort launch: ") + hipGetErrorString((hipError_t)e); return WH_ERR_HIP; }
+    return WH_OK;
+}
+
+// The same sort for callers that cannot allocate (HIP graph capture, serving loops): the second permutation buffer and the
+// count table are this device's copy of the file-scope `scratch` array instead of context buffers that grow on demand.
+// No hipMalloc / hipFree / event creation on any path; nothing in the scratch has to start at zero (every word the kernels
+// read in a pass was written earlier in that pass), so calls of different sizes may follow each other.  All calls on one
+// GPU share the array: two that overlap in time (two contexts, two streams) race.
+int32_t wh_sort_by_testing_id_noalloc_dev(wh_ctx *c, const uint8_t *d_ids, uint64_t n, uint32_t *d_order, const uint8_t *d_tags,
+                                          uint32_t tag_bytes, uint8_t *d_sorted_ids, uint8_t *d_sorted_tags) {
+    if (!c || (n && (!d_ids || !d_order))) return WH_ERR_PARAM;
+    if (n > SORT_NOALLOC_MAX_N) { c->err = "allocation-free sort: more than 2^20 ids (use wh_sort_by_testing_id_dev)"; return WH_ERR_PARAM; }
+    if (d_sorted_tags && (!d_tags || !tag_bytes || tag_bytes % 16)) return WH_ERR_PARAM;
+    if (!c->d_scratch) return WH_ERR_STATE;
+    if (!n) return WH_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint32_t *tmp = c->d_scratch, *hist = c->d_scratch + SORT_NOALLOC_MAX_N;
+    int e = launch_sort_by_id(d_ids, (uint32_t)n, d_order, tmp, hist, c->stream);
+    if (!e && d_sorted_ids) e = launch_sort_gather(d_ids, 16, d_order, (uint32_t)n, d_sorted_ids, c->stream);
+    if (!e && d_sorted_tags) e = launch_sort_gather(d_tags, tag_bytes, d_order, (uint32_t)n, d_sorted_tags, c->stream);
+    if (e) { c->err = "allocation-free sort: kernel launch failed"; return WH_ERR_HIP; }
     return WH_OK;
 }
 

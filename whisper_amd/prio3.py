@@ -275,6 +275,11 @@ class Prio3:
         self._chk(lib.wh_sort_by_testing_id_dev(self._ctx, d_ids, n, d_order, d_tags, tag_bytes, d_sorted_ids, d_sorted_tags),
                   "sort_by_testing_id_dev")
 
+    def sort_by_testing_id_noalloc_dev(self, d_ids, n, d_order, d_tags=None, tag_bytes=16, d_sorted_ids=None, d_sorted_tags=None):
+        """The same sort through the entry point that allocates nothing (scratch in a file-scope device array, n <= 2^20)."""
+        self._chk(lib.wh_sort_by_testing_id_noalloc_dev(self._ctx, d_ids, n, d_order, d_tags, tag_bytes, d_sorted_ids, d_sorted_tags),
+                  "sort_by_testing_id_noalloc_dev")
+
     def keep_mask_dev(self, d_ids, n, bad_ids, d_keep):
         """keep[i] = testing id i not in bad_ids (iterable of ints, the group test's verdict); device buffers as raw pointers."""
         bad = np.frombuffer(b"".join(int(x).to_bytes(16, "little") for x in bad_ids), np.uint8) if len(bad_ids) else np.zeros(0, np.uint8)
