@@ -25,15 +25,8 @@ namespace wh {
 // ------------------------------------------------------------------------------- helpers ----
 __device__ __forceinline__ uint64_t be64(const uint8_t *p) { return __builtin_bswap64(ld64(p)); }
 
-// 16-byte load from a pointer known to be in global memory (report bytes and workspace rows,
-// reached through descriptors the compiler cannot see through): global_load instead of
-// flat_load, so that loads issued ahead of their use are counted by vmcnt alone.
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef u32x4 u32x4_unaligned __attribute__((aligned(1)));
-__device__ __forceinline__ F128 ld128g(const uint8_t *p) {
-    const u32x4 v = *(const __attribute__((address_space(1))) u32x4_unaligned *)p;
-    return F128{v.x | ((uint64_t)v.y << 32), v.z | ((uint64_t)v.w << 32)};
-}
+// ld128g (keccak.hpp): 16-byte load from a pointer known to be in global memory -- global_load instead of flat_load, so that
+// loads issued ahead of their use are counted by vmcnt alone.
 
 __device__ __forceinline__ F128 shfl_xor_f(const F128 &v, int mask) {
     F128 r;

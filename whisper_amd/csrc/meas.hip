@@ -23,7 +23,7 @@
 namespace wh {
 
 __device__ __forceinline__ uint32_t dpp_prev(uint32_t x) {      // x of lane - 1 (rows of 16 lanes)
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);   // the first lane of a row reads 0: it is a squeezer
 }
 struct W2 { uint32_t lo, hi; };
 __device__ __forceinline__ W2 fetch_prev(uint64_t w) { return W2{dpp_prev((uint32_t)w), dpp_prev((uint32_t)(w >> 32))}; }
@@ -38,11 +38,74 @@ __device__ __forceinline__ void xor_shifted(uint64_t &b, const W2 &cur, uint32_t
 
 enum : uint32_t { LANE_FULL = 0, LANE_SQUEEZE = 1, LANE_ABSORB = 2 };
 
+// Equal shares of a SIMD's issue slots.  A SIMD picks the oldest ready wavefront first: of the three sponge wavefronts it
+// holds, two run at nearly full speed and the third gets what is left, so the two finish early and the third then runs
+// its chain alone at the issue rate of a lone wavefront (measured with tools/meas_bench.hip: the three end after 17, 26
+// and 36 ms).  Each wavefront therefore sets its user priority from the shader clock, which the wavefronts of a SIMD
+// read alike: epochs of 2^WH_PRIO_EPOCH_LOG2 cycles, rank = (wave slot + epoch) mod 3, so that at any time the three hold
+// the three ranks and over three epochs each has had every rank.
+#ifndef WH_PRIO_EPOCH_LOG2
+#define WH_PRIO_EPOCH_LOG2 21
+#endif
+__device__ __forceinline__ uint32_t wave_slot() { return __builtin_amdgcn_s_getreg((3 << 11) | 4); }   // HW_ID.wave_id
+__device__ __forceinline__ void rotate_prio(uint32_t slot) {
+#ifndef WH_MEAS_NO_ROTATE
+    const uint32_t epoch = (uint32_t)(__builtin_amdgcn_s_memtime() >> WH_PRIO_EPOCH_LOG2);
+    const uint32_t r = __builtin_amdgcn_readfirstlane((slot + epoch) % 3);
+    if (r == 0) __builtin_amdgcn_s_setprio(0);
+    else if (r == 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(2);
+#endif
+}
+
+// one rate block as ten 16-byte loads and one 8-byte load (any alignment)
+__device__ __forceinline__ void load_block(uint64_t (&w)[RATE_WORDS], const uint8_t *p) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        const F128 t = ld128g(p + 16 * i);
+        w[2 * i] = t.lo; w[2 * i + 1] = t.hi;
+    }
+    w[20] = ld64g(p + 160);
+}
+// nb whole rate blocks from p into a sponge that sits on a block boundary (pos == 0); the next block's loads are in
+// flight under the permutation
+__device__ __forceinline__ void absorb_whole_blocks(SpongeG &s, const uint8_t *p, uint32_t nb, uint32_t slot) {
+    if (!nb) return;
+    uint64_t w[RATE_WORDS];
+    load_block(w, p);
+#pragma unroll 1
+    for (uint32_t b = 0; b < nb; b++) {
+#pragma unroll
+        for (int i = 0; i < (int)RATE_WORDS; i++) s.st[i] ^= w[i];
+        p += SHAKE128_RATE;
+        if (b + 1 < nb) load_block(w, p);
+        rotate_prio(slot);
+        keccak_f1600(s.st);
+    }
+}
+
+// Diagnostic build only (tools/meas_bench.hip): lane 0 of every wavefront stamps the shader clock and the 100 MHz
+// real-time counter around its sponge loop into a buffer nothing else reads; the product build has no stamp.
+#ifdef WH_MEAS_CLOCKPROBE
+#define WH_STAMP(slot)                                                                            \
+    do {                                                                                          \
+        if ((threadIdx.x & 63) == 0) {                                                            \
+            g_probe[6ull * (gid >> 6) + 2 * (slot)] = __builtin_amdgcn_s_memtime();               \
+            g_probe[6ull * (gid >> 6) + 2 * (slot) + 1] = __builtin_amdgcn_s_memrealtime();       \
+            g_probe[6ull * (gid >> 6) + 4] = __builtin_amdgcn_s_getreg(63492);  /* HW_ID */       \
+            g_probe[6ull * (gid >> 6) + 5] = __builtin_amdgcn_s_getreg(63508);  /* XCC_ID */      \
+        }                                                                                         \
+    } while (0)
+#else
+#define WH_STAMP(slot) do { } while (0)
+#endif
+
 // mode 0: Leader-role reports (whole absorb) and Helper pairs; mode 1: the dirty list (whole absorb from the
 // rows k_expand wrote).
 template <uint32_t mode>
 __device__ __forceinline__ void meas_body(const Prio3Dev &P, const Workspace &W, int32_t *status) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t slot = wave_slot();
     uint32_t i, kind;
     if (mode == 1) {
         if (gid >= W.counters[2]) return;
@@ -79,6 +142,7 @@ __device__ __forceinline__ void meas_body(const Prio3Dev &P, const Workspace &W,
             s.pos++;
         }
     }
+    WH_STAMP(0);
     const uint8_t *rest = d.meas;                    // what phase 2 still has to absorb
     uint32_t rest_len = 16u * P.input_len;
     uint32_t dirty = 0;
@@ -89,17 +153,18 @@ __device__ __forceinline__ void meas_body(const Prio3Dev &P, const Workspace &W,
         if (even) s.finalize();                      // first output block
         uint8_t *out = const_cast<uint8_t *>(d.meas);
         const uint32_t iters = P.input_len / 21;     // 21 chunks = two rate blocks
-#define WH_PUT(lo_, hi_)                                                                         \
-        do {                                                                                     \
-            const uint64_t l_ = (lo_), h_ = (hi_);                                               \
-            dirty |= even && !(h_ < bound.hi || (h_ == bound.hi && l_ < bound.lo));              \
-            if (even) st128g(out, F128{l_, h_});                                                 \
-            out += 16;                                                                           \
-        } while (0)
+        // Words 15..20 of the squeezed block reach the absorber only after ITS permutation: they wait in LDS (48 B per
+        // lane, written and read by the same wavefront, so no barrier), not in registers across the permutation.
+        __shared__ uint64_t park[256 * 6];
+        uint64_t *mine = park + threadIdx.x, *prev = park + (threadIdx.x ? threadIdx.x - 1 : 0);
+        // Rejection check (prng.rs:73-99), cheap form: the running maximum of the chunks' top 32 bits; only a half-iteration
+        // that saw a top word >= the bound's (probability 2^-32 per chunk with the real p) looks at the chunks exactly.
+        const uint32_t bound_top = (uint32_t)(bound.hi >> 32);
+#define WH_EXACT(lo_, hi_) dirty |= !((hi_) < bound.hi || ((hi_) == bound.hi && (lo_) < bound.lo))
 #pragma unroll 1
         for (uint32_t it = 0; it < iters; it++) {
-            W2 t[6];
-            uint32_t prev_hi = 0;
+            uint32_t prev_hi = 0, top = 0;
+            rotate_prio(slot);
             // even block e[0..20] is in the squeezer's state: absorber words 5..20 take e[0..15]
 #pragma unroll
             for (int w = 0; w < 16; w++) {
@@ -108,15 +173,28 @@ __device__ __forceinline__ void meas_body(const Prio3Dev &P, const Workspace &W,
                 prev_hi = c.hi;
             }
 #pragma unroll
-            for (int w = 0; w < 6; w++) t[w] = fetch_prev(s.st[15 + w]);
+            for (int w = 0; w < 6; w++) mine[256 * w] = s.st[15 + w];
 #pragma unroll
-            for (int c = 0; c < 10; c++) WH_PUT(s.st[2 * c], s.st[2 * c + 1]);
+            for (int c = 0; c < 10; c++) top = max(top, (uint32_t)(s.st[2 * c + 1] >> 32));
+            if (__builtin_expect(__any(top >= bound_top), 0)) {
+#pragma unroll
+                for (int c = 0; c < 10; c++) WH_EXACT(s.st[2 * c], s.st[2 * c + 1]);
+            }
+            if (even) {
+#pragma unroll
+                for (int c = 0; c < 10; c++) st128g(out + 16 * c, F128{s.st[2 * c], s.st[2 * c + 1]});
+            }
             const uint64_t carry = s.st[20];
             keccak_f1600(s.st);
             // absorber: words 0..4 of its next block from e[15..20]; then o[0..15] into words 5..20
+            {
+                uint64_t t[6];
 #pragma unroll
-            for (int w = 0; w < 5; w++) xor_shifted(s.st[w], t[w + 1], t[w].hi, m);
-            prev_hi = t[5].hi;
+                for (int w = 0; w < 6; w++) t[w] = prev[256 * w];
+#pragma unroll
+                for (int w = 0; w < 5; w++) xor_shifted(s.st[w], W2{(uint32_t)t[w + 1], (uint32_t)(t[w + 1] >> 32)}, (uint32_t)(t[w] >> 32), m);
+                prev_hi = (uint32_t)(t[5] >> 32);
+            }
 #pragma unroll
             for (int w = 0; w < 16; w++) {
                 const W2 c = fetch_prev(s.st[w]);
@@ -124,15 +202,32 @@ __device__ __forceinline__ void meas_body(const Prio3Dev &P, const Workspace &W,
                 prev_hi = c.hi;
             }
 #pragma unroll
-            for (int w = 0; w < 6; w++) t[w] = fetch_prev(s.st[15 + w]);
-            WH_PUT(carry, s.st[0]);
+            for (int w = 0; w < 6; w++) mine[256 * w] = s.st[15 + w];
+            top = (uint32_t)(s.st[0] >> 32);
 #pragma unroll
-            for (int c = 0; c < 10; c++) WH_PUT(s.st[2 * c + 1], s.st[2 * c + 2]);
+            for (int c = 0; c < 10; c++) top = max(top, (uint32_t)(s.st[2 * c + 2] >> 32));
+            if (__builtin_expect(__any(top >= bound_top), 0)) {
+                WH_EXACT(carry, s.st[0]);
+#pragma unroll
+                for (int c = 0; c < 10; c++) WH_EXACT(s.st[2 * c + 1], s.st[2 * c + 2]);
+            }
+            if (even) {
+                st128g(out + 160, F128{carry, s.st[0]});
+#pragma unroll
+                for (int c = 0; c < 10; c++) st128g(out + 176 + 16 * c, F128{s.st[2 * c + 1], s.st[2 * c + 2]});
+            }
+            out += 336;
             keccak_f1600(s.st);
+            {
+                uint64_t t[6];
 #pragma unroll
-            for (int w = 0; w < 5; w++) xor_shifted(s.st[w], t[w + 1], t[w].hi, m);
-            xor_shifted(s.st[5], W2{0, 0}, t[5].hi, m);
+                for (int w = 0; w < 6; w++) t[w] = prev[256 * w];
+#pragma unroll
+                for (int w = 0; w < 5; w++) xor_shifted(s.st[w], W2{(uint32_t)t[w + 1], (uint32_t)(t[w + 1] >> 32)}, (uint32_t)(t[w] >> 32), m);
+                xor_shifted(s.st[5], W2{0, 0}, (uint32_t)(t[5] >> 32), m);
+            }
         }
+        dirty &= even;
         // the last r < 21 chunks: squeezed word by word, absorbed from memory in phase 2
         const uint32_t r = P.input_len - 21 * iters;
         if (even) {
@@ -143,12 +238,15 @@ __device__ __forceinline__ void meas_body(const Prio3Dev &P, const Workspace &W,
                     if (wpos == RATE_WORDS) { keccak_f1600(s.st); wpos = 0; }
                     v[h] = s.get_word(wpos++);
                 }
-                WH_PUT(v[0], v[1]);
+                WH_EXACT(v[0], v[1]);
+                st128g(out, F128{v[0], v[1]});
+                out += 16;
             }
         }
-#undef WH_PUT
+#undef WH_EXACT
         // a rejected chunk anywhere makes the whole hand-over invalid: the absorber reports it
         dirty = __builtin_amdgcn_update_dpp(0, (int)dirty, 0x111, 0xf, 0xf, false) | dirty;
+        WH_STAMP(1);
         if (even) return;
         if (dirty) {
             W.dirty[atomicAdd(&W.counters[2], 1u)] = i;
@@ -160,8 +258,16 @@ __device__ __forceinline__ void meas_body(const Prio3Dev &P, const Workspace &W,
         rest_len = 16u * r;
     }
     // phase 2: Leader (and mode 1): the whole share; absorber lanes: the tail
-    s.absorb3(rest, rest_len, nullptr, 0, nullptr, 0);
+    {
+        // up to the next block boundary the generic way, whole blocks with the explicit loop, the tail the generic way
+        const uint32_t head = min(rest_len, s.pos ? SHAKE128_RATE - s.pos : 0u);     // pos is wave-uniform
+        s.absorb(rest, head);
+        const uint32_t nb = (rest_len - head) / SHAKE128_RATE;
+        absorb_whole_blocks(s, rest + head, nb, slot);
+        s.absorb(rest + head + nb * SHAKE128_RATE, rest_len - head - nb * SHAKE128_RATE);
+    }
     s.finalize();
+    if (kind == LANE_FULL) WH_STAMP(1);
     const F128 sd = F128{s.st[0], s.st[1]};
     // the locally computed part vs the one in the public share (prio3.rs:2790-2805); the
     // descriptor is read again here rather than held in registers across the long loops
