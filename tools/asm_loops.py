@@ -2,7 +2,7 @@
 import re, sys, collections
 L = open(sys.argv[1]).read().split('\n')
 start = [i for i, l in enumerate(L) if sys.argv[2] in l and re.match(r'^_Z\S+:', l)][0]
-end = next(i for i in range(start, len(L)) if 's_endpgm' in L[i])
+end = next(i for i in range(start, len(L)) if L[i].startswith('.Lfunc_end'))
 body = L[start:end]
 labels = {l.split(':')[0]: i for i, l in enumerate(body) if re.match(r'^\.LBB\d+_\d+:', l)}
 print('kernel lines', len(body))

@@ -208,10 +208,44 @@ WH_HD void mad_acc(uint64_t &acc, uint32_t a, uint32_t b) {
 #endif
 }
 WH_HD void f_lazy_mac(Lazy &a, const uint32_t (&x)[5], const uint32_t (&w)[5]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // all 25 products in ONE asm statement: hipcc puts an s_nop between two asm statements that follow each other
+    // directly (175 of them per four elements in the query kernel's loop), none inside a statement.  Consecutive
+    // instructions never touch the same column.
+    asm("v_mad_u64_u32 %0, vcc, %9, %14, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %9, %15, %1\n\t"
+        "v_mad_u64_u32 %2, vcc, %9, %16, %2\n\t"
+        "v_mad_u64_u32 %3, vcc, %9, %17, %3\n\t"
+        "v_mad_u64_u32 %4, vcc, %9, %18, %4\n\t"
+        "v_mad_u64_u32 %1, vcc, %10, %14, %1\n\t"
+        "v_mad_u64_u32 %2, vcc, %10, %15, %2\n\t"
+        "v_mad_u64_u32 %3, vcc, %10, %16, %3\n\t"
+        "v_mad_u64_u32 %4, vcc, %10, %17, %4\n\t"
+        "v_mad_u64_u32 %5, vcc, %10, %18, %5\n\t"
+        "v_mad_u64_u32 %2, vcc, %11, %14, %2\n\t"
+        "v_mad_u64_u32 %3, vcc, %11, %15, %3\n\t"
+        "v_mad_u64_u32 %4, vcc, %11, %16, %4\n\t"
+        "v_mad_u64_u32 %5, vcc, %11, %17, %5\n\t"
+        "v_mad_u64_u32 %6, vcc, %11, %18, %6\n\t"
+        "v_mad_u64_u32 %3, vcc, %12, %14, %3\n\t"
+        "v_mad_u64_u32 %4, vcc, %12, %15, %4\n\t"
+        "v_mad_u64_u32 %5, vcc, %12, %16, %5\n\t"
+        "v_mad_u64_u32 %6, vcc, %12, %17, %6\n\t"
+        "v_mad_u64_u32 %7, vcc, %12, %18, %7\n\t"
+        "v_mad_u64_u32 %4, vcc, %13, %14, %4\n\t"
+        "v_mad_u64_u32 %5, vcc, %13, %15, %5\n\t"
+        "v_mad_u64_u32 %6, vcc, %13, %16, %6\n\t"
+        "v_mad_u64_u32 %7, vcc, %13, %17, %7\n\t"
+        "v_mad_u64_u32 %8, vcc, %13, %18, %8"
+        : "+v"(a.c[0]), "+v"(a.c[1]), "+v"(a.c[2]), "+v"(a.c[3]), "+v"(a.c[4]), "+v"(a.c[5]), "+v"(a.c[6]), "+v"(a.c[7]), "+v"(a.c[8])
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4])
+        : "vcc");
+#else
 #pragma unroll
     for (int i = 0; i < 5; i++)
 #pragma unroll
         for (int j = 0; j < 5; j++) mad_acc(a.c[i + j], x[i], w[j]);
+#endif
 }
 WH_HD F128 f_lazy_reduce(const Lazy &a) {
     // carry the column sums into 26-bit digits l[0..10] (value < 2^271)

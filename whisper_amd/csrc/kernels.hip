@@ -611,12 +611,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     F128 tag = f_zero();
     LazySmall sum_x;                            // Histogram's sum check
     f_small_zero(sum_x);
-    uint32_t susp = 0;                          // a top word of all ones: look again, exactly
+    uint32_t top = 0;                           // largest top word seen; all ones: look again, exactly
     const bool trunc = P.circuit == CIRCUIT_SUMVEC;
     // truncate through LDS: the 64 slots of a wave hold whole outputs, 8 consecutive elements per lane
     const bool lds_trunc = trunc && (P.bits == 8 || P.bits == 16 || P.bits == 32) && (P.chunk & 63) == 0;
     const uint32_t lpo = P.bits >> 3;           // lanes per output in that case
 
+    // every call is whole and every wave's 64 slots exist: no bounds to check inside the stream (uniform over the launch)
+    const bool fast = P.input_len == calls * P.chunk && (P.chunk & 63) == 0 && (calls & 7) == 0;
     for (uint32_t kb = 64 * wave; kb < P.chunk; kb += 64 * S) {
         const uint32_t k = kb + lane;
         Lazy cA, cB;
@@ -624,42 +626,32 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         f_lazy_zero(cB);
         F128 Af = f_zero(), Bf = f_zero();
         uint32_t since = 0;
-        // element of call jj (0-based) in this lane's slot, or element 0 (masked) outside the share
-        auto fetch = [&](uint32_t jj, bool &ok) -> F128 {
-            const uint64_t idx = (uint64_t)jj * P.chunk + k;
-            ok = jj < calls && k < P.chunk && idx < P.input_len;
-            return ld128g(d.meas + 16ull * (ok ? idx : 0));
+        uint32_t xl[4][5];
+        // element u of the group of four that starts at call jj: range pre-check, limbs, Histogram's sum, truncate staging
+        // (c = position of the call inside its tile of eight; stage_slot(64 c + lane) = 68 c + lane + lane / 16)
+        uint4 *stage_lane = stage + lane + (lane >> 4);
+        auto take = [&](uint32_t c, int u, const F128 &v) {
+            top = max(top, (uint32_t)(v.hi >> 32));
+            f_split26(v, xl[u]);
+            if (HIST) f_small_mac(sum_x, v, 1u);
+            if (lds_trunc)
+                stage_lane[68 * c] = make_uint4((uint32_t)v.lo, (uint32_t)(v.lo >> 32), (uint32_t)v.hi, (uint32_t)(v.hi >> 32));
         };
-        F128 xb[4];
-        bool okb[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) xb[u] = fetch(u, okb[u]);
-        for (uint32_t jj = 0; jj < calls; jj += 4) {
-            // cut the four elements that have arrived into limbs, put the next four loads in
-            // flight straight away, then do the arithmetic under them
-            uint32_t xl[4][5];
+        // the two wire sums of the four elements, weights of calls jj .. jj + 3 from LDS (broadcast reads)
+        auto wires = [&](uint32_t jj, bool clamp) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                F128 v = xb[u];
-                if (!okb[u]) v = f_zero();
-                susp |= (uint32_t)(v.hi >> 32) == 0xffffffffu;
-                f_split26(v, xl[u]);
-                if (HIST) f_small_mac(sum_x, v, 1u);
-                if (lds_trunc)
-                    stage[stage_slot(((jj & 4) + u) * 64 + lane)] =
-                        make_uint4((uint32_t)v.lo, (uint32_t)(v.lo >> 32), (uint32_t)v.hi, (uint32_t)(v.hi >> 32));
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) xb[u] = fetch(jj + u + 4, okb[u]);
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t jc = jj + u < calls ? jj + u : calls - 1;   // a call past the end has x = 0
+                const uint32_t jc = !clamp || jj + u < calls ? jj + u : calls - 1;   // a call past the end has x = 0
                 const uint4 *src = reinterpret_cast<const uint4 *>(wl + 12 * jc);
                 const uint4 w0 = src[0], w1 = src[1], w2 = src[2];
                 const uint32_t wL[5] = {w0.x, w0.y, w0.z, w0.w, w1.x};
                 const uint32_t wM[5] = {w1.y, w1.z, w1.w, w2.x, w2.y};
+#if defined(WH_Q_EXP) && WH_Q_EXP == 1     // timing experiment (results invalid): no wire arithmetic
+                cA.c[0] += xl[u][0] ^ wM[0]; cB.c[0] += xl[u][4] ^ wL[0];
+#else
                 f_lazy_mac(cA, xl[u], wM);
                 f_lazy_mac(cB, xl[u], wL);
+#endif
             }
             since += 4;
             if (since + 4 > LAZY_MAX_TERMS) {
@@ -669,28 +661,81 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
                 f_lazy_zero(cB);
                 since = 0;
             }
-            if (lds_trunc && ((jj & 4) || jj + 4 >= calls)) {
-                // a tile of eight calls is parked: lane handles positions 8 lane .. 8 lane + 7
-                // (call t = lane / 8 of the tile, slots 8 (lane % 8) ..), lpo lanes make one output
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                const uint32_t j0 = jj & ~7u, t = lane >> 3, kk0 = (lane & 7) * 8;
-                const uint32_t l0 = kk0 & (P.bits - 1);
-                LazySmall acc;
-                f_small_zero(acc);
+        };
+        // a tile of eight calls is parked: lane handles positions 8 lane .. 8 lane + 7
+        // (call t = lane / 8 of the tile, slots 8 (lane % 8) ..), lpo lanes make one output
+        auto tile = [&](uint32_t jj) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t j0 = jj & ~7u, t = lane >> 3, kk0 = (lane & 7) * 8;
+            const uint32_t l0 = kk0 & (P.bits - 1);
+            LazySmall acc;
+            f_small_zero(acc);
 #pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const uint4 v = stage[stage_slot(lane * 8 + q)];
-                    f_small_mac(acc, F128{v.x | ((uint64_t)v.y << 32), v.z | ((uint64_t)v.w << 32)}, 1u << (l0 + q));
+            for (int q = 0; q < 8; q++) {
+                const uint4 v = stage[stage_slot(lane * 8 + q)];
+                f_small_mac(acc, F128{v.x | ((uint64_t)v.y << 32), v.z | ((uint64_t)v.w << 32)}, 1u << (l0 + q));
+            }
+            for (uint32_t m = 1; m < lpo; m <<= 1)
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc.c[q] += __shfl_xor((unsigned long long)acc.c[q], m, 64);
+            const uint64_t idx0 = (uint64_t)(j0 + t) * P.chunk + kb + (kk0 - l0);
+            const uint64_t e = idx0 / P.bits;
+            if ((lane & (lpo - 1)) == 0 && j0 + t < calls && e < P.output_len) out_row[e] = f_small_reduce(acc);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        };
+        if (fast) {
+            const uint64_t stride = 16ull * P.chunk;
+#if defined(WH_Q_EXP) && WH_Q_EXP == 2     // timing experiment (results invalid): every load hits the same lines
+            const uint8_t *p = d.meas + 16ull * lane;
+#define WH_Q_ADV(p_) (void)0
+#else
+            const uint8_t *p = d.meas + 16ull * k;
+#define WH_Q_ADV(p_) p_ += 4 * stride
+#endif
+            F128 xb[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) xb[u] = ld128g(p + u * stride);
+            WH_Q_ADV(p);
+            for (uint32_t jj = 0; jj < calls; jj += 8) {
+                // cut the four elements that have arrived into limbs, put the next four loads in
+                // flight straight away, then do the arithmetic under them; twice per tile of eight calls
+#pragma unroll
+                for (int u = 0; u < 4; u++) take(u, u, xb[u]);
+#pragma unroll
+                for (int u = 0; u < 4; u++) xb[u] = ld128g(p + u * stride);
+                WH_Q_ADV(p);
+                wires(jj, false);
+#pragma unroll
+                for (int u = 0; u < 4; u++) take(4 + u, u, xb[u]);
+                if (jj + 8 < calls) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) xb[u] = ld128g(p + u * stride);
+                    WH_Q_ADV(p);
                 }
-                for (uint32_t m = 1; m < lpo; m <<= 1)
+                wires(jj + 4, false);
+                if (lds_trunc) tile(jj + 4);
+            }
+#undef WH_Q_ADV
+        } else {
+            // element of call jj (0-based) in this lane's slot, or element 0 (masked) outside the share
+            auto fetch = [&](uint32_t jj, bool &ok) -> F128 {
+                const uint64_t idx = (uint64_t)jj * P.chunk + k;
+                ok = jj < calls && k < P.chunk && idx < P.input_len;
+                return ld128g(d.meas + 16ull * (ok ? idx : 0));
+            };
+            F128 xb[4];
+            bool okb[4];
 #pragma unroll
-                    for (int q = 0; q < 4; q++) acc.c[q] += __shfl_xor((unsigned long long)acc.c[q], m, 64);
-                const uint64_t idx0 = (uint64_t)(j0 + t) * P.chunk + kb + (kk0 - l0);
-                const uint64_t e = idx0 / P.bits;
-                if ((lane & (lpo - 1)) == 0 && j0 + t < calls && e < P.output_len) out_row[e] = f_small_reduce(acc);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
+            for (int u = 0; u < 4; u++) xb[u] = fetch(u, okb[u]);
+            for (uint32_t jj = 0; jj < calls; jj += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) take((jj & 4) + u, u, okb[u] ? xb[u] : f_zero());
+#pragma unroll
+                for (int u = 0; u < 4; u++) xb[u] = fetch(jj + u + 4, okb[u]);
+                wires(jj, true);
+                if (lds_trunc && ((jj & 4) || jj + 4 >= calls)) tile(jj);
             }
         }
         // this lane's slot: seeds (call 0), differences against the public proof, RLC
@@ -715,7 +760,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         if (kb + 64 * S < P.chunk) rho_kb = f_mul(rho_kb, pw->rho64[S]);
     }
     // the exact range check of the share, in the rare case that a top word was all ones
-    if (wave_or(susp))
+    if (wave_or(top == 0xffffffffu))
         for (uint32_t e = lane; e < P.input_len; e += 64) {
             F128 x = ld128g(d.meas + 16ull * e);
             bad |= !f_in_range(x.lo, x.hi);
