@@ -24,7 +24,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import whisper_amd as W  # noqa: E402
-from whisper_amd.dist import all_gather_partials  # noqa: E402
+from whisper_amd.dist import all_gather_partials, allgather_reduce_dev, comm_init_from_torch, hh_allreduce_u32_dev  # noqa: E402
 
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from common import VK, make_reports  # noqa: E402  (deterministic synthetic clients; no oracle involved)
@@ -182,6 +182,12 @@ def main():
                 self.sids, self.stags = torch.zeros_like(self.ids), torch.zeros_like(self.tags)
                 self.keep = torch.zeros(n, dtype=torch.uint8, device=dev)
     lanes = [Lane(vdaf)] + [Lane(W.Prio3(params, device=local_rank)) for _ in range(max(1, args.in_flight) - 1)]
+    # N > 1: the combine goes through the library's own RCCL binding (wh_comm_init / wh_prio3_allgather_reduce_dev); the gloo
+    # rehearsal (several ranks on one GPU, which RCCL refuses) keeps torch's all-gather + wh_f128_sum_rows_dev
+    wh_comm = world > 1 and backend == "nccl"
+    if wh_comm:
+        for ln in lanes:
+            comm_init_from_torch(ln.vdaf)
     d_status = lanes[0].status
     torch.cuda.synchronize()
     bad_ids = []
@@ -203,8 +209,10 @@ def main():
             ln.vdaf.aggregate_dev(ln.keep.data_ptr(), ln.agg.data_ptr())
         else:
             ln.vdaf.aggregate_dev(d_keep.data_ptr(), ln.agg.data_ptr())
-        if world > 1:
-            # RCCL all-gather of the raw limbs on the context stream, then the on-GPU mod-p row sum
+        if wh_comm:
+            # RCCL all-gather of the raw limbs on the context stream, then the on-GPU mod-p row sum, inside the library
+            allgather_reduce_dev(ln.vdaf, ln.agg.data_ptr(), ln.total.data_ptr())
+        elif world > 1:
             with torch.cuda.stream(ln.ext):
                 rows = all_gather_partials(ln.agg)
             ln.vdaf.sum_rows_dev(rows.data_ptr(), world, s.output_len, None, ln.total.data_ptr())
@@ -346,6 +354,9 @@ def bench_hh(args, rank, local_rank, world, dev, backend):
     keys[:, :8] = ((rank << 40) + np.arange(n, dtype=np.uint64) % clients).view(np.uint8).reshape(n, 8)   # client ids
     h = hh.HeavyHitters(N, device=local_rank)
     ext = torch.cuda.ExternalStream(h.stream, device=dev)
+    wh_comm = world > 1 and backend == "nccl"            # the library's own RCCL binding; the gloo rehearsal keeps torch's
+    if wh_comm:
+        comm_init_from_torch(h)
     d_keys = torch.from_numpy(keys).to(dev)
     d_dat = torch.empty((n, N, 258), dtype=torch.int32, device=dev)
     d_tags = torch.zeros((n, 64), dtype=torch.uint8, device=dev)
@@ -363,7 +374,9 @@ def bench_hh(args, rank, local_rank, world, dev, backend):
         for r in range(reps):                            # one sketch per repetition (aggregate_hhs)
             h.bucket_sum_u32_dev(d_dat.data_ptr() + 4 * r * clients * words, d_keep.data_ptr() + r * clients, clients, words,
                                  d_acc.data_ptr() + 4 * r * words)
-        if world > 1:
+        if wh_comm:
+            hh_allreduce_u32_dev(h, d_acc.data_ptr(), reps * words)
+        elif world > 1:
             with torch.cuda.stream(ext):
                 all_reduce_sketch_u32(d_acc)
 

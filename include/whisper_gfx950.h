@@ -65,7 +65,8 @@ enum {
     WH_ERR_HIP = -100,
     WH_ERR_NO_DEVICE = -101,
     WH_ERR_STATE = -102,
-    WH_ERR_UNSUPPORTED = -103
+    WH_ERR_UNSUPPORTED = -103,
+    WH_ERR_COMM = -104        /* RCCL reported an error (wh_last_error has its text) */
 };
 
 /* ---- context ---- */
@@ -77,6 +78,14 @@ int32_t wh_prio3_sizes_of(const wh_prio3_params *params, wh_prio3_sizes *out);
 const char *wh_last_error(const wh_ctx *ctx);
 /* the HIP stream (hipStream_t) the context launches on, for callers that time or order work */
 void *wh_ctx_stream(wh_ctx *ctx);
+/* replaces: nothing in the reference, where `Prio3: Clone + Send + Sync` is called from 32 tokio tasks and a rayon pool at
+ * once (server-batch-prio3/src/main.rs:282-335, 138-156).  Every entry point takes the context's (recursive) lock while it
+ * works, so threads may share a context; a task that needs a sequence undisturbed -- prepare, the host's group test, then
+ * aggregate of THAT batch -- brackets it with wh_ctx_lock / wh_ctx_unlock and the other tasks queue behind it.  A server gives
+ * each GPU a few contexts (each owns a workspace) and lets its tasks pick one: tests/cpp/funnel_gpu.cpp runs 32 threads
+ * over two contexts. */
+int32_t wh_ctx_lock(wh_ctx *ctx);
+int32_t wh_ctx_unlock(wh_ctx *ctx);
 
 /* ---- batched verification ---- */
 /* replaces: the per-report loop of run_vdaf_prepare{,_rayon} over prepare_encoded_key
@@ -85,7 +94,10 @@ void *wh_ctx_stream(wh_ctx *ctx);
  *   + Prf::compute_prf + tag negation for agg_id != 0.
  * blob/offsets: n encoded reports back to back, offsets[n+1] (bytes).  All pointers are DEVICE
  * pointers; nothing is copied to the host and the call returns after enqueueing on the context
- * stream (wh_ctx_synchronize to wait).
+ * stream (wh_ctx_synchronize to wait).  Precondition: d_blob holds at least max(offsets) bytes.  A
+ * pair offsets[i+1] < offsets[i] is an empty report (status WH_ERR_SHORT), never a read outside the blob.
+ * The status array may be freed or reused once the call has been waited for or once later work has been
+ * enqueued on the context stream: the context keeps its own copy for wh_prio3_aggregate*.
  *   tags        n*16   proof tags (already negated for Helper-role reports)
  *   testing_ids n*16   u128 LE
  *   status      n      int32 per report
@@ -99,7 +111,8 @@ int32_t wh_prio3_prepare_batch(wh_ctx *ctx, const uint8_t verify_key[16], const 
                                const uint64_t *offsets, uint64_t n, uint8_t *tags, uint8_t *testing_ids,
                                int32_t *status);
 /* replaces: Prio3::prepare_batched's second return value (OutputShare).  Copies the n*output_len
- * out-share elements of the last batch to the host. */
+ * out-share elements of the last batch to the host.  WH_ERR_STATE unless the last call that used the
+ * context's workspace was a prepare call or wh_flp_query_batch (wh_client_shard_many_gpu leaves nothing). */
 int32_t wh_prio3_out_shares(wh_ctx *ctx, uint8_t *out_shares);
 
 /* ---- un-batched Prio3 (draft-07), the paper's baseline server ---- */
@@ -152,13 +165,41 @@ int32_t wh_flp_prove(const wh_prio3_params *params, const uint8_t *input, const 
 /* replaces: the merge loop over reports whose testing id is not in the bad set
  * (server-batch-prio3/src/main.rs:108-118, 173-183; Aggregatable::merge vdaf.rs:658-676;
  * Prio3::aggregate prio3.rs:2445-2456).  keep[n]: 1 = aggregate, 0 = skip (NULL = keep all).
- * Reports with non-zero status are never aggregated. */
+ * Reports with non-zero status are never aggregated.  WH_ERR_STATE unless the context's last workspace
+ * user was wh_prio3_prepare_batch[_dev] or wh_prio3_prepare_init_batch[_dev] (+ finish): wh_flp_query_batch and
+ * wh_client_shard_many_gpu overwrite the out shares. */
 int32_t wh_prio3_aggregate_dev(wh_ctx *ctx, const uint8_t *d_keep, uint8_t *d_agg);
 int32_t wh_prio3_aggregate(wh_ctx *ctx, const uint8_t *keep, uint8_t *agg);
 /* replaces: AggregateShare::merge across partial aggregates (main.rs:327-335); with one process
  * per GPU the rows are the RCCL all-gathered per-GPU partials.  d_rows[n_rows][len] -> d_out[len]. */
 int32_t wh_f128_sum_rows_dev(wh_ctx *ctx, const uint8_t *d_rows, uint64_t n_rows, uint32_t len,
                              const uint8_t *d_keep, uint8_t *d_out);
+
+/* ---- several GPUs in one server: one context per GPU, combined over RCCL / xGMI ---- */
+/* replaces: the merge of the per-task partial aggregates (server-batch-prio3/src/main.rs:327-335; AggregateShare::merge,
+ * vdaf.rs:658-676) once the batch is sharded over the GPUs of a node -- reports shard by index with no data-path
+ * collective, each GPU verifies and aggregates its shard (wh_prio3_aggregate_dev), then the output_len*16-byte partials
+ * are all-gathered as raw limbs (RCCL has no mod-p reduction) and summed mod p on every GPU.
+ * wh_comm_unique_id: rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the other ranks over any channel the
+ * server already has.  wh_comm_init binds the context to rank `rank` of `world` (ncclCommInitRank on the context's GPU;
+ * collective: all ranks call it).  id == NULL with world == 1 is a lone GPU without RCCL; a non-NULL id with world == 1 runs
+ * the same collectives through RCCL.  RCCL is loaded at the first of these calls (WH_ERR_UNSUPPORTED if it is absent). */
+#define WH_COMM_ID_BYTES 128
+int32_t wh_comm_unique_id(uint8_t id[WH_COMM_ID_BYTES]);
+int32_t wh_comm_init(wh_ctx *ctx, const uint8_t *id, int32_t rank, int32_t world);
+int32_t wh_comm_destroy(wh_ctx *ctx);
+int32_t wh_comm_rank(wh_ctx *ctx, int32_t *rank, int32_t *world);
+/* d_partial[output_len] (this GPU's aggregate share, device) -> d_agg[output_len] = sum over ranks mod p, on every rank;
+ * asynchronous on the context stream.  The _f128_ form takes the row length (any Field128 row). */
+int32_t wh_prio3_allgather_reduce_dev(wh_ctx *ctx, const uint8_t *d_partial, uint8_t *d_agg);
+int32_t wh_f128_allgather_reduce_dev(wh_ctx *ctx, const uint8_t *d_partial, uint32_t len, uint8_t *d_out);
+/* wh_prio3_aggregate (host keep mask, host result) of the last batch on this GPU followed by the combine: what a Rust
+ * task holding `keep` calls instead of the loop at main.rs:108-118 + the merge at :327-335. */
+int32_t wh_prio3_allgather_reduce(wh_ctx *ctx, const uint8_t *keep, uint8_t *agg);
+/* replaces: the element-wise sum of sketches held by several GPUs of one server (the same Bucket::add / CountSketch::insert
+ * arithmetic as server-hh/src/main.rs:72-104, 192-197, 374-394): in-place all-reduce of d_sketch[words] u32 counters with
+ * wrapping addition (ncclSum on ncclUint32 is exact in Z/2^32). */
+int32_t wh_hh_allreduce_u32_dev(wh_ctx *ctx, uint32_t *d_sketch, uint64_t words);
 
 /* ---- heavy hitters ---- */
 /* replaces: aggregate_hhs' rayon reduce of Vec<Bucket<u32>> (server-hh/src/main.rs:72-104;
@@ -225,7 +266,8 @@ int32_t wh_sort_by_testing_id(wh_ctx *ctx, const uint8_t *ids, uint64_t n, uint3
 /* replaces: the `if !bad_set.contains(&tag.testing_id)` filter of the merge loops (server-batch-prio3/src/main.rs:108-118,
  * 173-183; server-hh/src/main.rs:79-103): d_keep[i] = 0 iff the testing id of report i (d_ids[n][16], device, 16-byte aligned)
  * is one of the n_bad ids the group test returned (bad_ids[n_bad][16], little endian, HOST memory, any order), else 1.
- * The mask then goes to wh_prio3_aggregate_dev / wh_hh_aggregate_dev. */
+ * The mask then goes to wh_prio3_aggregate_dev / wh_hh_aggregate_dev.  Asynchronous: the ids are copied into pinned
+ * staging owned by the context before the call returns, so bad_ids may be reused at once. */
 int32_t wh_keep_mask_dev(wh_ctx *ctx, const uint8_t *d_ids, uint64_t n, const uint8_t *bad_ids, uint64_t n_bad, uint8_t *d_keep);
 
 int32_t wh_ctx_synchronize(wh_ctx *ctx);

@@ -37,3 +37,13 @@ def test_server_hh_cpp_two_servers():
     the heavy string is read back (CountSketch::recover)."""
     r = subprocess.run([_binary("test_server_hh")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_funnel_32_threads_two_contexts_and_combine_cpp():
+    """include/whisper_gfx950.h's caller funnel: 32 threads (the reference's 32 tokio tasks, server-batch-prio3/src/main.rs:282-335)
+    over two contexts with wh_ctx_lock brackets, each getting its own batch's results; the multi-GPU combine behind the C ABI
+    with one rank, without RCCL and through RCCL."""
+    r = subprocess.run([_binary("funnel_gpu")], capture_output=True, text=True, timeout=300)
+    # RCCL prints its version banner first
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("OK"), r.stdout + r.stderr

@@ -50,7 +50,10 @@ struct wh_ctx {
     bool aes_valid = false;
     F128 *d_out_shares = nullptr;  // [out_cap][output_len]
     uint64_t out_cap = 0, n_last = 0;
-    int32_t *d_status_last = nullptr;  // status of the last batch (device, caller-owned or ours)
+    // which entry point produced the out shares the context holds: aggregate / out_shares / prepare_finish refuse anything else
+    enum Producer { NONE = 0, PREPARE_BATCH, PREPARE_INIT, FLP_QUERY } producer = NONE;
+    int32_t *d_status_last = nullptr;  // status of the last batch: always context-owned memory (d_status_keep or d_status_own)
+    int32_t *d_status_keep = nullptr; uint64_t status_keep_cap = 0;   // copy of a caller-owned status array (the _dev entry points)
     int32_t *d_status_own = nullptr; uint64_t status_cap = 0;
     uint8_t *d_keep_eff = nullptr; uint64_t keep_cap = 0;
     F128 *d_partials = nullptr; uint64_t partials_cap = 0;
@@ -81,7 +84,17 @@ struct wh_ctx {
     uint32_t *d_sort_tmp = nullptr; uint64_t sort_tmp_cap = 0;
     uint32_t *d_sort_hist = nullptr; uint64_t sort_hist_cap = 0;
     uint64_t *d_bad_ids = nullptr; uint64_t bad_ids_cap = 0;
+    hipEvent_t ev_bad = nullptr; bool bad_sorted_busy = false;
+    unsigned __int128 *h_bad = nullptr; uint64_t h_bad_cap = 0;   // pinned host staging of wh_keep_mask_dev: lives until the next call, so its copy stays asynchronous
+    // scratch of the host-buffer entry points (grow on demand, freed with the context)
+    uint8_t *d_tmp_a = nullptr; uint64_t tmp_a_cap = 0;
+    uint8_t *d_tmp_b = nullptr; uint64_t tmp_b_cap = 0;
+    uint8_t *d_tmp_c = nullptr; uint64_t tmp_c_cap = 0;
     uint32_t *d_scratch = nullptr;      // this device's copy of the file-scope `scratch` array (not owned)
+    // every entry point holds this while it works on the context, so threads may share a context; a caller that needs a
+    // sequence of calls undisturbed (prepare ... aggregate) brackets it with wh_ctx_lock / wh_ctx_unlock (recursive)
+    std::recursive_mutex mu;
+    void *comm = nullptr;        // multi-GPU state (comm.hip)
     double k_ms[WH_NUM_KERNELS] = {0};
     uint64_t k_launches[WH_NUM_KERNELS] = {0};
     std::string err;
@@ -89,6 +102,7 @@ struct wh_ctx {
 
 namespace {
 
+#define WH_LOCK(ctx) std::lock_guard<std::recursive_mutex> wh_lock_guard_(ctx->mu)
 #define HIPCHK(ctx, call)                                                                         \
     do {                                                                                          \
         hipError_t e_ = (call);                                                                   \
@@ -113,6 +127,17 @@ int32_t scratch_of_device(wh_ctx *c) {
         g_scratch_ptr[c->device] = static_cast<uint32_t *>(p);
     }
     c->d_scratch = g_scratch_ptr[c->device];
+    return WH_OK;
+}
+
+// The context remembers the per-report status of its last batch for the aggregation's keep mask.  A caller-owned array
+// may be freed or reused between the two calls, so its contents are copied (in stream order, after the kernels that
+// write it) into context memory; `keep` must have been sized before the launches.
+int32_t remember_status(wh_ctx *c, const int32_t *d_status, uint64_t n) {
+    if (!n) { c->d_status_last = nullptr; return WH_OK; }
+    if (d_status == c->d_status_own) { c->d_status_last = c->d_status_own; return WH_OK; }
+    HIPCHK(c, hipMemcpyAsync(c->d_status_keep, d_status, 4 * n, hipMemcpyDeviceToDevice, c->stream));
+    c->d_status_last = c->d_status_keep;
     return WH_OK;
 }
 
@@ -233,6 +258,16 @@ QueryLaunch query_launch(const wh_ctx *c, bool base) {
 
 }  // namespace
 
+// what comm.hip needs of a context
+namespace wh {
+int ctx_device(wh_ctx *c) { return c->device; }
+hipStream_t ctx_stream(wh_ctx *c) { return c->stream; }
+void **ctx_comm_slot(wh_ctx *c) { return &c->comm; }
+std::recursive_mutex &ctx_mutex(wh_ctx *c) { return c->mu; }
+void ctx_set_error(wh_ctx *c, const std::string &what) { c->err = what; }
+uint32_t ctx_output_len(wh_ctx *c) { return c->z.output_len; }
+}
+
 extern "C" {
 
 int32_t wh_prio3_sizes_of(const wh_prio3_params *p, wh_prio3_sizes *out) {
@@ -264,6 +299,7 @@ int32_t wh_ctx_create(int32_t device_id, const wh_prio3_params *params, wh_ctx *
     if (hipStreamCreate(&c->stream2) != hipSuccess) return fail(WH_ERR_HIP);
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(WH_ERR_HIP);
     if (hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) return fail(WH_ERR_HIP);
+    if (hipEventCreateWithFlags(&c->ev_bad, hipEventDisableTiming) != hipSuccess) return fail(WH_ERR_HIP);
     c->err.reserve(256);                 // later error texts need no host allocation either
     if ((rc = scratch_of_device(c))) return fail(rc);
 
@@ -300,27 +336,35 @@ int32_t wh_ctx_create(int32_t device_id, const wh_prio3_params *params, wh_ctx *
 void wh_ctx_destroy(wh_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
+    wh_comm_destroy(c);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->stream2) hipStreamSynchronize(c->stream2);
-    void *ptrs[] = {c->d_omega, c->d_stab, c->d_aes, c->d_out_shares, c->d_status_own, c->d_keep_eff, c->d_partials,
+    void *ptrs[] = {c->d_omega, c->d_stab, c->d_aes, c->d_out_shares, c->d_status_own, c->d_status_keep, c->d_tmp_a, c->d_tmp_b, c->d_tmp_c, c->d_keep_eff, c->d_partials,
                     c->d_blob, c->d_offsets, c->d_tags, c->d_ids, c->d_prep, c->W.desc, c->W.scal, c->W.weights, c->W.wlimbs, c->W.pows, c->W.rlc,
                     c->W.hrows, c->W.hlist, c->W.llist, c->W.dirty, c->W.counters,
                     c->d_omega2m, c->d_twist, c->d_hh_tab, c->hh_w.tpc, c->hh_w.proofblk, c->hh_w.supd, c->hh_w.buckg, c->d_hh_dat, c->d_hh_keys, c->d_hh_tags,
                     c->d_hh_ids, c->d_hh_status, c->d_hh_keep, c->d_hh_acc, c->d_sort_tmp, c->d_sort_hist, c->d_bad_ids};
     for (void *p : ptrs) if (p) hipFree(p);
+    if (c->h_bad) hipHostFree(c->h_bad);
     for (auto &e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->ev_bad) hipEventDestroy(c->ev_bad);
     if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
 
 const char *wh_last_error(const wh_ctx *c) { return c ? c->err.c_str() : "null context"; }
+// the funnel for concurrent callers (32 tokio tasks, a rayon pool): tasks queue on the context; recursive, so the calls
+// inside a bracket still take it
+int32_t wh_ctx_lock(wh_ctx *c) { if (!c) return WH_ERR_PARAM; c->mu.lock(); return WH_OK; }
+int32_t wh_ctx_unlock(wh_ctx *c) { if (!c) return WH_ERR_PARAM; c->mu.unlock(); return WH_OK; }
 void *wh_ctx_stream(wh_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int32_t wh_ctx_synchronize(wh_ctx *c) {
     if (!c) return WH_ERR_PARAM;
+    WH_LOCK(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return WH_OK;
 }
@@ -329,6 +373,7 @@ int32_t wh_prio3_prepare_batch_dev(wh_ctx *c, const uint8_t verify_key[16], cons
                                    const uint64_t *d_offsets, uint64_t n, uint8_t *d_tags, uint8_t *d_ids,
                                    int32_t *d_status) {
     if (!c || !verify_key || (n && (!d_blob || !d_offsets || !d_tags || !d_ids || !d_status))) return WH_ERR_PARAM;
+    WH_LOCK(c);
     if (n > 0xfffffff0ull || c->params.num_aggregators != 2) return WH_ERR_PARAM;
     HIPCHK(c, hipSetDevice(c->device));
     const HostSizes &z = c->z;
@@ -338,6 +383,8 @@ int32_t wh_prio3_prepare_batch_dev(wh_ctx *c, const uint8_t verify_key[16], cons
     // allocations first (none inside the launch sequence once the context is warm)
     if ((rc = alloc_workspace(c, pick_cap(c, n)))) return rc;
     if ((rc = ensure(c, c->d_out_shares, c->out_cap, (n ? n : 1) * (uint64_t)z.output_len))) return rc;
+    if (d_status != c->d_status_own && (rc = ensure(c, c->d_status_keep, c->status_keep_cap, n ? n : 1))) return rc;
+    c->producer = wh_ctx::NONE; c->n_last = 0;           // until this batch is enqueued completely
     if (!c->aes_valid || memcmp(c->d_aes_key, verify_key, 16)) {
         uint8_t t[432];
         aes_tables(verify_key, t);
@@ -348,8 +395,6 @@ int32_t wh_prio3_prepare_batch_dev(wh_ctx *c, const uint8_t verify_key[16], cons
     }
     uint64_t vk0, vk1;
     memcpy(&vk0, verify_key, 8); memcpy(&vk1, verify_key + 8, 8);
-    c->n_last = n;
-    c->d_status_last = d_status;
     const QueryLaunch q = query_launch(c, false);
     if (!q.fn) { c->err = "circuit has too many gadget calls for the query kernel's LDS rows"; return WH_ERR_UNSUPPORTED; }
     uint8_t *d_out = reinterpret_cast<uint8_t *>(c->d_out_shares);
@@ -386,12 +431,15 @@ int32_t wh_prio3_prepare_batch_dev(wh_ctx *c, const uint8_t verify_key[16], cons
                            tags_b, out_b, d_status + base); }
         HIPCHK(c, hipGetLastError());
     }
+    if ((rc = remember_status(c, d_status, n))) return rc;
+    c->n_last = n; c->producer = wh_ctx::PREPARE_BATCH;
     return WH_OK;
 }
 
 int32_t wh_prio3_prepare_init_batch_dev(wh_ctx *c, const uint8_t verify_key[16], const uint8_t *d_blob,
                                         const uint64_t *d_offsets, uint64_t n, uint8_t *d_prep, int32_t *d_status) {
     if (!c || !verify_key || (n && (!d_blob || !d_offsets || !d_prep || !d_status))) return WH_ERR_PARAM;
+    WH_LOCK(c);
     if (n > 0xfffffff0ull) return WH_ERR_PARAM;
     HIPCHK(c, hipSetDevice(c->device));
     const HostSizes &z = c->z;
@@ -401,13 +449,13 @@ int32_t wh_prio3_prepare_init_batch_dev(wh_ctx *c, const uint8_t verify_key[16],
     if ((rc = alloc_workspace(c, pick_cap(c, n)))) return rc;
     if ((rc = ensure(c, c->d_out_shares, c->out_cap, (n ? n : 1) * (uint64_t)z.output_len))) return rc;
     if (n > c->cap) { c->err = "prepare_init keeps its state in the workspace: one sub-batch only"; return WH_ERR_UNSUPPORTED; }
+    if (d_status != c->d_status_own && (rc = ensure(c, c->d_status_keep, c->status_keep_cap, n ? n : 1))) return rc;
     uint64_t vk0, vk1;
     memcpy(&vk0, verify_key, 8); memcpy(&vk1, verify_key + 8, 8);
-    c->n_last = n;
-    c->d_status_last = d_status;
+    c->producer = wh_ctx::NONE; c->n_last = 0;
     const QueryLaunch q = query_launch(c, true);
     if (!q.fn) { c->err = "circuit has too many gadget calls for the query kernel's LDS rows"; return WH_ERR_UNSUPPORTED; }
-    if (!n) return WH_OK;
+    if (!n) { c->d_status_last = nullptr; c->producer = wh_ctx::PREPARE_INIT; return WH_OK; }
     const uint32_t nb = (uint32_t)n, npad = (nb + 255) / 256 * 256;
     uint8_t *d_out = reinterpret_cast<uint8_t *>(c->d_out_shares);
     HIPCHK(c, hipMemsetAsync(c->W.counters, 0, 64, c->stream));
@@ -422,14 +470,17 @@ int32_t wh_prio3_prepare_init_batch_dev(wh_ctx *c, const uint8_t verify_key[16],
     hipLaunchKernelGGL(q.fn, dim3(q.polyeval ? (nb + 3) / 4 : nb), dim3(64 * q.waves), q.lds, c->stream, c->P, c->W, d_prep,
                        d_out, d_status); }
     HIPCHK(c, hipGetLastError());
+    if ((rc = remember_status(c, d_status, n))) return rc;
+    c->n_last = n; c->producer = wh_ctx::PREPARE_INIT;
     return WH_OK;
 }
 
 int32_t wh_prio3_prepare_init_batch(wh_ctx *c, const uint8_t verify_key[16], const uint8_t *blob, const uint64_t *offsets,
                                     uint64_t n, uint8_t *prep_shares, int32_t *status) {
     if (!c || !verify_key || (n && (!blob || !offsets || !prep_shares || !status))) return WH_ERR_PARAM;
+    WH_LOCK(c);
     HIPCHK(c, hipSetDevice(c->device));
-    if (n == 0) { c->n_last = 0; return WH_OK; }
+    if (n == 0) { c->n_last = 0; c->d_status_last = nullptr; c->producer = wh_ctx::PREPARE_INIT; return WH_OK; }
     for (uint64_t i = 0; i < n; i++) if (offsets[i + 1] < offsets[i]) return WH_ERR_PARAM;
     int32_t rc;
     const uint64_t base0 = offsets[0], bytes = offsets[n] - base0, prep_bytes = 16ull * (c->z.verifier_len + 1) * n;
@@ -452,39 +503,35 @@ int32_t wh_prio3_prepare_init_batch(wh_ctx *c, const uint8_t verify_key[16], con
 int32_t wh_prio3_prepare_finish_batch(wh_ctx *c, const uint8_t *const *prep_shares, uint64_t n, uint8_t *prep_msgs,
                                       int32_t *status) {
     if (!c || (n && (!prep_shares || !prep_msgs || !status))) return WH_ERR_PARAM;
+    WH_LOCK(c);
     HIPCHK(c, hipSetDevice(c->device));
-    if (n != c->n_last || c->P.mode != 1 || (n && c->d_status_last != c->d_status_own)) return WH_ERR_STATE;
+    if (c->producer != wh_ctx::PREPARE_INIT || n != c->n_last || (n && c->d_status_last != c->d_status_own)) return WH_ERR_STATE;
     if (n == 0) return WH_OK;
     const uint32_t na = c->params.num_aggregators;
     const uint64_t prep_bytes = 16ull * (c->z.verifier_len + 1) * n;
+    for (uint32_t a = 0; a < na; a++) if (!prep_shares[a]) return WH_ERR_PARAM;
     int32_t rc;
-    uint8_t *d_all = nullptr, *d_msgs = nullptr;
-    const uint8_t **d_ptrs = nullptr;
-    HIPCHK(c, hipMalloc((void **)&d_all, prep_bytes * na));
-    HIPCHK(c, hipMalloc((void **)&d_msgs, 16 * n));
-    HIPCHK(c, hipMalloc((void **)&d_ptrs, sizeof(uint8_t *) * na));
+    // scratch from the context (grown on demand): all prepare shares, the messages, the row pointers
+    if ((rc = ensure(c, c->d_tmp_a, c->tmp_a_cap, prep_bytes * na))) return rc;
+    if ((rc = ensure(c, c->d_tmp_b, c->tmp_b_cap, 16 * n))) return rc;
+    if ((rc = ensure(c, c->d_tmp_c, c->tmp_c_cap, sizeof(uint8_t *) * na))) return rc;
+    uint8_t *d_all = c->d_tmp_a, *d_msgs = c->d_tmp_b;
+    const uint8_t **d_ptrs = reinterpret_cast<const uint8_t **>(c->d_tmp_c);
     std::vector<const uint8_t *> ptrs(na);
-    rc = WH_OK;
-    hipError_t e = hipSuccess;
-    for (uint32_t a = 0; a < na && e == hipSuccess; a++) {
-        if (!prep_shares[a]) { rc = WH_ERR_PARAM; break; }
+    for (uint32_t a = 0; a < na; a++) {
         ptrs[a] = d_all + prep_bytes * a;
-        e = hipMemcpyAsync(d_all + prep_bytes * a, prep_shares[a], prep_bytes, hipMemcpyHostToDevice, c->stream);
+        HIPCHK(c, hipMemcpyAsync(d_all + prep_bytes * a, prep_shares[a], prep_bytes, hipMemcpyHostToDevice, c->stream));
     }
-    if (!rc && e == hipSuccess) e = hipMemcpyAsync(d_ptrs, ptrs.data(), sizeof(uint8_t *) * na, hipMemcpyHostToDevice, c->stream);
-    if (!rc && e == hipSuccess) e = hipMemsetAsync(d_msgs, 0, 16 * n, c->stream);
-    if (!rc && e == hipSuccess) {
-        hipLaunchKernelGGL(k_finish_base, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, c->stream, c->P, c->W, d_ptrs, (uint32_t)n,
-                           d_msgs, c->d_status_own);
-        e = hipGetLastError();
-    }
-    if (!rc && e == hipSuccess) e = hipMemcpyAsync(prep_msgs, d_msgs, 16 * n, hipMemcpyDeviceToHost, c->stream);
-    if (!rc && e == hipSuccess) e = hipMemcpyAsync(status, c->d_status_own, 4 * n, hipMemcpyDeviceToHost, c->stream);
-    hipError_t e2 = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess) e = e2;
-    hipFree(d_all); hipFree(d_msgs); hipFree(d_ptrs);
-    if (!rc && e != hipSuccess) { c->err = hipGetErrorString(e); rc = WH_ERR_HIP; }
-    return rc;
+    HIPCHK(c, hipMemcpyAsync(d_ptrs, ptrs.data(), sizeof(uint8_t *) * na, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));          // `ptrs` is a local
+    HIPCHK(c, hipMemsetAsync(d_msgs, 0, 16 * n, c->stream));
+    hipLaunchKernelGGL(k_finish_base, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, c->stream, c->P, c->W, d_ptrs, (uint32_t)n,
+                       d_msgs, c->d_status_own);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(prep_msgs, d_msgs, 16 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(status, c->d_status_own, 4 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return WH_OK;
 }
 
 // Type::query on rows already in HBM: d_in[n][input_len], d_pf[n][proof_len], d_qr[n][1], d_jr[n][jr_len] -> d_ver[n][verifier_len]
@@ -497,12 +544,12 @@ static int32_t flp_query_dev(wh_ctx *c, const uint8_t *d_in, const uint8_t *d_pf
     if ((rc = alloc_workspace(c, pick_cap(c, n)))) return rc;
     if (n > c->cap) { c->err = "flp query: one sub-batch only"; return WH_ERR_UNSUPPORTED; }
     if ((rc = ensure(c, c->d_out_shares, c->out_cap, (n ? n : 1) * (uint64_t)z.output_len))) return rc;
-    c->n_last = n;
+    // Type::query leaves Type::truncate of its inputs for wh_prio3_out_shares; there is nothing to aggregate
+    c->n_last = n; c->d_status_last = nullptr; c->producer = wh_ctx::FLP_QUERY;
     if (!n) return WH_OK;
     const QueryLaunch q = query_launch(c, true);
     if (!q.fn) { c->err = "circuit has too many gadget calls for the query kernel's LDS rows"; return WH_ERR_UNSUPPORTED; }
     HIPCHK(c, hipMemsetAsync(c->W.counters, 0, 64, c->stream));
-    c->d_status_last = d_status;
     const uint32_t nb = (uint32_t)n, npad = (nb + 255) / 256 * 256;
     hipLaunchKernelGGL(k_flp_setup, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, d_in, d_pf, d_qr, d_jr, nb, d_status);
     hipLaunchKernelGGL(q.fn, dim3(q.polyeval ? (nb + 3) / 4 : nb), dim3(64 * q.waves), q.lds, c->stream, c->P, c->W, d_ver,
@@ -514,6 +561,7 @@ static int32_t flp_query_dev(wh_ctx *c, const uint8_t *d_in, const uint8_t *d_pf
 int32_t wh_flp_query_batch(wh_ctx *c, const uint8_t *input, const uint8_t *proof, const uint8_t *query_rand,
                            const uint8_t *joint_rand, uint32_t num_shares, uint64_t n, uint8_t *verifier, int32_t *status) {
     if (!c || !num_shares || (n && (!input || !proof || !query_rand || !joint_rand || !verifier || !status))) return WH_ERR_PARAM;
+    WH_LOCK(c);
     if (n > 0xfffffff0ull) return WH_ERR_PARAM;
     HIPCHK(c, hipSetDevice(c->device));
     const HostSizes &z = c->z;
@@ -565,6 +613,7 @@ static int32_t prove_tables(wh_ctx *c, ProveDev &D) {
 int32_t wh_flp_prove_batch(wh_ctx *c, const uint8_t *input, const uint8_t *prove_rand, const uint8_t *joint_rand, uint64_t n,
                            uint8_t *proof, int32_t *status) {
     if (!c || (n && (!input || !prove_rand || !proof || !status)) || (n && c->z.jr_len && !joint_rand)) return WH_ERR_PARAM;
+    WH_LOCK(c);
     if (n > 0x7fffffffull) return WH_ERR_PARAM;
     HIPCHK(c, hipSetDevice(c->device));
     const HostSizes &z = c->z;
@@ -597,6 +646,7 @@ int32_t wh_client_shard_many_gpu(wh_ctx *c, const uint64_t *measurements, uint32
                                  const uint8_t *rands, uint64_t first_client_id, uint64_t n, uint8_t *leader_reports,
                                  uint8_t *helper_reports) {
     if (!c || (n && (!measurements || !nonces || !rands || !leader_reports || !helper_reports))) return WH_ERR_PARAM;
+    WH_LOCK(c);
     if (n > 0x7fffffffull) return WH_ERR_PARAM;
     const HostSizes &z = c->z;
     const wh_prio3_params &p = c->params;
@@ -673,7 +723,7 @@ int32_t wh_client_shard_many_gpu(wh_ctx *c, const uint64_t *measurements, uint32
     }
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(arena);
-    c->n_last = 0; c->d_status_last = nullptr;        // the query kernels ran on scratch of this call
+    c->n_last = 0; c->d_status_last = nullptr; c->producer = wh_ctx::NONE;   // the query kernels ran on scratch of this call
     if (!rc && e != hipSuccess) { c->err = std::string("shard: ") + hipGetErrorString(e); rc = WH_ERR_HIP; }
     return rc;
 }
@@ -682,6 +732,7 @@ int32_t wh_client_shard_many_gpu(wh_ctx *c, const uint64_t *measurements, uint32
 int32_t wh_sort_by_testing_id_dev(wh_ctx *c, const uint8_t *d_ids, uint64_t n, uint32_t *d_order, const uint8_t *d_tags,
                                   uint32_t tag_bytes, uint8_t *d_sorted_ids, uint8_t *d_sorted_tags) {
     if (!c || (n && (!d_ids || !d_order))) return WH_ERR_PARAM;
+    WH_LOCK(c);
     if (n > (1ull << 28)) return WH_ERR_PARAM;
     if (d_sorted_tags && (!d_tags || !tag_bytes || tag_bytes % 16)) return WH_ERR_PARAM;
     if (!n) return WH_OK;
@@ -706,6 +757,7 @@ int32_t wh_sort_by_testing_id_dev(wh_ctx *c, const uint8_t *d_ids, uint64_t n, u
 int32_t wh_sort_by_testing_id_noalloc_dev(wh_ctx *c, const uint8_t *d_ids, uint64_t n, uint32_t *d_order, const uint8_t *d_tags,
                                           uint32_t tag_bytes, uint8_t *d_sorted_ids, uint8_t *d_sorted_tags) {
     if (!c || (n && (!d_ids || !d_order))) return WH_ERR_PARAM;
+    WH_LOCK(c);
     if (n > SORT_NOALLOC_MAX_N) { c->err = "allocation-free sort: more than 2^20 ids (use wh_sort_by_testing_id_dev)"; return WH_ERR_PARAM; }
     if (d_sorted_tags && (!d_tags || !tag_bytes || tag_bytes % 16)) return WH_ERR_PARAM;
     if (!c->d_scratch) return WH_ERR_STATE;
@@ -722,18 +774,27 @@ int32_t wh_sort_by_testing_id_noalloc_dev(wh_ctx *c, const uint8_t *d_ids, uint6
 // the filter of the servers' merge loops: keep[i] = !bad_set.contains(testing_id[i])
 int32_t wh_keep_mask_dev(wh_ctx *c, const uint8_t *d_ids, uint64_t n, const uint8_t *bad_ids, uint64_t n_bad, uint8_t *d_keep) {
     if (!c || (n && (!d_ids || !d_keep)) || (n_bad && !bad_ids)) return WH_ERR_PARAM;
+    WH_LOCK(c);
     if (n > 0xfffffff0ull || n_bad > 0xfffffff0ull) return WH_ERR_PARAM;
     if (!n) return WH_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    typedef unsigned __int128 u128;
-    std::vector<u128> bad(n_bad);
-    if (n_bad) memcpy(bad.data(), bad_ids, 16 * n_bad);
-    std::sort(bad.begin(), bad.end());
     int32_t rc;
     if ((rc = ensure(c, c->d_bad_ids, c->bad_ids_cap, 2 * (n_bad ? n_bad : 1)))) return rc;
     if (n_bad) {
-        HIPCHK(c, hipMemcpyAsync(c->d_bad_ids, bad.data(), 16 * n_bad, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));         // `bad` is a local
+        // the sorted ids stay in the context until the next call, so the copy can stay asynchronous; an earlier call's copy
+        // out of the same vector must have left the host first
+        if (c->bad_sorted_busy) HIPCHK(c, hipEventSynchronize(c->ev_bad));
+        if (n_bad > c->h_bad_cap) {
+            if (c->h_bad) HIPCHK(c, hipHostFree(c->h_bad));
+            c->h_bad = nullptr; c->h_bad_cap = 0;
+            HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_bad), 16 * n_bad, hipHostMallocDefault));
+            c->h_bad_cap = n_bad;
+        }
+        memcpy(c->h_bad, bad_ids, 16 * n_bad);
+        std::sort(c->h_bad, c->h_bad + n_bad);
+        HIPCHK(c, hipMemcpyAsync(c->d_bad_ids, c->h_bad, 16 * n_bad, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipEventRecord(c->ev_bad, c->stream));
+        c->bad_sorted_busy = true;
     }
     const int e = launch_keep_mask(d_ids, (uint32_t)n, c->d_bad_ids, (uint32_t)n_bad, d_keep, c->stream);
     if (e) { c->err = std::string("keep mask launch: ") + hipGetErrorString((hipError_t)e); return WH_ERR_HIP; }
@@ -742,53 +803,46 @@ int32_t wh_keep_mask_dev(wh_ctx *c, const uint8_t *d_ids, uint64_t n, const uint
 
 int32_t wh_sort_by_testing_id(wh_ctx *c, const uint8_t *ids, uint64_t n, uint32_t *order) {
     if (!c || (n && (!ids || !order))) return WH_ERR_PARAM;
+    WH_LOCK(c);
     if (n > (1ull << 28)) return WH_ERR_PARAM;
     if (!n) return WH_OK;
     HIPCHK(c, hipSetDevice(c->device));
     int32_t rc;
     if ((rc = ensure(c, c->d_ids, c->ids_cap, 16 * n))) return rc;
-    uint32_t *d_order = nullptr;
-    HIPCHK(c, hipMalloc((void **)&d_order, 4 * n));
-    hipError_t e = hipMemcpyAsync(c->d_ids, ids, 16 * n, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) {
-        rc = wh_sort_by_testing_id_dev(c, c->d_ids, n, d_order, nullptr, 0, nullptr, nullptr);
-        if (!rc) e = hipMemcpyAsync(order, d_order, 4 * n, hipMemcpyDeviceToHost, c->stream);
-    }
-    hipError_t e2 = hipStreamSynchronize(c->stream);
-    (void)hipFree(d_order);
-    if (rc) return rc;
-    if (e == hipSuccess) e = e2;
-    if (e != hipSuccess) { c->err = std::string("sort: ") + hipGetErrorString(e); return WH_ERR_HIP; }
+    if ((rc = ensure(c, c->d_tmp_a, c->tmp_a_cap, 4 * n))) return rc;
+    uint32_t *d_order = reinterpret_cast<uint32_t *>(c->d_tmp_a);
+    HIPCHK(c, hipMemcpyAsync(c->d_ids, ids, 16 * n, hipMemcpyHostToDevice, c->stream));
+    if ((rc = wh_sort_by_testing_id_dev(c, c->d_ids, n, d_order, nullptr, 0, nullptr, nullptr))) return rc;
+    HIPCHK(c, hipMemcpyAsync(order, d_order, 4 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return WH_OK;
 }
 
 int32_t wh_flp_decide_batch(wh_ctx *c, const uint8_t *verifier, uint64_t n, int32_t *decision) {
     if (!c || (n && (!verifier || !decision))) return WH_ERR_PARAM;
+    WH_LOCK(c);
     if (n > 0xfffffff0ull) return WH_ERR_PARAM;
     HIPCHK(c, hipSetDevice(c->device));
     if (!n) return WH_OK;
     const uint64_t ver_b = 16ull * c->z.verifier_len * n;
-    uint8_t *d_v = nullptr; int32_t *d_ok = nullptr;
-    HIPCHK(c, hipMalloc((void **)&d_v, ver_b));
-    HIPCHK(c, hipMalloc((void **)&d_ok, 4 * n));
-    hipError_t e = hipMemcpyAsync(d_v, verifier, ver_b, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_flp_decide, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, c->stream, c->P, d_v, (uint32_t)n, d_ok);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(decision, d_ok, 4 * n, hipMemcpyDeviceToHost, c->stream);
-    hipError_t e2 = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess) e = e2;
-    hipFree(d_v); hipFree(d_ok);
-    if (e != hipSuccess) { c->err = hipGetErrorString(e); return WH_ERR_HIP; }
+    int32_t rc;
+    if ((rc = ensure(c, c->d_tmp_a, c->tmp_a_cap, ver_b))) return rc;
+    if ((rc = ensure(c, c->d_tmp_b, c->tmp_b_cap, 4 * n))) return rc;
+    uint8_t *d_v = c->d_tmp_a; int32_t *d_ok = reinterpret_cast<int32_t *>(c->d_tmp_b);
+    HIPCHK(c, hipMemcpyAsync(d_v, verifier, ver_b, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_flp_decide, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, c->stream, c->P, d_v, (uint32_t)n, d_ok);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(decision, d_ok, 4 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return WH_OK;
 }
 
 int32_t wh_prio3_prepare_batch(wh_ctx *c, const uint8_t verify_key[16], const uint8_t *blob, const uint64_t *offsets,
                                uint64_t n, uint8_t *tags, uint8_t *ids, int32_t *status) {
     if (!c || !verify_key || (n && (!blob || !offsets || !tags || !ids || !status))) return WH_ERR_PARAM;
+    WH_LOCK(c);
     HIPCHK(c, hipSetDevice(c->device));
-    if (n == 0) { c->n_last = 0; return WH_OK; }
+    if (n == 0) { c->n_last = 0; c->d_status_last = nullptr; c->producer = wh_ctx::PREPARE_BATCH; return WH_OK; }
     for (uint64_t i = 0; i < n; i++) if (offsets[i + 1] < offsets[i]) return WH_ERR_PARAM;
     int32_t rc;
     const uint64_t base0 = offsets[0], bytes = offsets[n] - base0;
@@ -813,6 +867,8 @@ int32_t wh_prio3_prepare_batch(wh_ctx *c, const uint8_t verify_key[16], const ui
 
 int32_t wh_prio3_out_shares(wh_ctx *c, uint8_t *out) {
     if (!c || !out) return WH_ERR_PARAM;
+    WH_LOCK(c);
+    if (c->producer == wh_ctx::NONE) return WH_ERR_STATE;
     if (!c->n_last) return WH_OK;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(out, c->d_out_shares, c->n_last * c->z.output_len * sizeof(F128), hipMemcpyDeviceToHost, c->stream));
@@ -844,7 +900,10 @@ static int32_t sum_rows(wh_ctx *c, const F128 *rows, const uint8_t *d_keep, uint
 
 int32_t wh_prio3_aggregate_dev(wh_ctx *c, const uint8_t *d_keep, uint8_t *d_agg) {
     if (!c || !d_agg) return WH_ERR_PARAM;
+    WH_LOCK(c);
     HIPCHK(c, hipSetDevice(c->device));
+    // only a prepare call leaves something to aggregate (not Type::query, not the sharder, which reuse the workspace)
+    if (c->producer != wh_ctx::PREPARE_BATCH && c->producer != wh_ctx::PREPARE_INIT) return WH_ERR_STATE;
     const uint64_t n = c->n_last;
     int32_t rc;
     if (n) {
@@ -857,29 +916,28 @@ int32_t wh_prio3_aggregate_dev(wh_ctx *c, const uint8_t *d_keep, uint8_t *d_agg)
 
 int32_t wh_prio3_aggregate(wh_ctx *c, const uint8_t *keep, uint8_t *agg) {
     if (!c || !agg) return WH_ERR_PARAM;
+    WH_LOCK(c);
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->producer != wh_ctx::PREPARE_BATCH && c->producer != wh_ctx::PREPARE_INIT) return WH_ERR_STATE;
     const uint64_t n = c->n_last, len = c->z.output_len;
-    uint8_t *d_keep = nullptr, *d_agg = nullptr;
-    HIPCHK(c, hipMalloc((void **)&d_agg, len * 16));
+    int32_t rc;
+    if ((rc = ensure(c, c->d_tmp_a, c->tmp_a_cap, len * 16))) return rc;
+    uint8_t *d_keep = nullptr, *d_agg = c->d_tmp_a;
     if (keep && n) {
-        HIPCHK(c, hipMalloc((void **)&d_keep, n));
+        if ((rc = ensure(c, c->d_tmp_b, c->tmp_b_cap, n))) return rc;
+        d_keep = c->d_tmp_b;
         HIPCHK(c, hipMemcpyAsync(d_keep, keep, n, hipMemcpyHostToDevice, c->stream));
     }
-    int32_t rc = wh_prio3_aggregate_dev(c, d_keep, d_agg);
-    if (!rc) {
-        hipError_t e = hipMemcpyAsync(agg, d_agg, len * 16, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) { c->err = hipGetErrorString(e); rc = WH_ERR_HIP; }
-    }
-    hipStreamSynchronize(c->stream);
-    if (d_keep) hipFree(d_keep);
-    hipFree(d_agg);
-    return rc;
+    if ((rc = wh_prio3_aggregate_dev(c, d_keep, d_agg))) return rc;
+    HIPCHK(c, hipMemcpyAsync(agg, d_agg, len * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return WH_OK;
 }
 
 int32_t wh_f128_sum_rows_dev(wh_ctx *c, const uint8_t *d_rows, uint64_t n_rows, uint32_t len, const uint8_t *d_keep,
                              uint8_t *d_out) {
     if (!c || !d_out || (n_rows && !d_rows) || !len) return WH_ERR_PARAM;
+    WH_LOCK(c);
     HIPCHK(c, hipSetDevice(c->device));
     return sum_rows(c, reinterpret_cast<const F128 *>(d_rows), d_keep, n_rows, len, reinterpret_cast<F128 *>(d_out));
 }
@@ -887,6 +945,7 @@ int32_t wh_f128_sum_rows_dev(wh_ctx *c, const uint8_t *d_rows, uint64_t n_rows, 
 static int32_t hh_sum(wh_ctx *c, const uint32_t *d_buckets, const uint8_t *d_keep, uint64_t n, uint64_t words,
                       uint32_t *d_acc, bool zero_first) {
     if (!c || !d_acc || !words || (n && !d_buckets)) return WH_ERR_PARAM;
+    WH_LOCK(c);
     HIPCHK(c, hipSetDevice(c->device));
     if (zero_first) HIPCHK(c, hipMemsetAsync(d_acc, 0, words * 4, c->stream));
     if (!n) return WH_OK;
@@ -959,6 +1018,7 @@ static int32_t hh_workspace(wh_ctx *c, uint64_t cap, uint32_t depth) {
 int32_t wh_hh_eval_and_check_batch_dev(wh_ctx *c, const uint8_t verify_key[16], const uint8_t *d_keys, uint64_t stride, uint64_t n,
                                        uint32_t depth, uint32_t *d_dat, uint8_t *d_tags, uint8_t *d_ids, int32_t *d_status) {
     if (!c || !verify_key || depth < 1 || depth > HH_MAX_DEPTH || (n && (!d_keys || !d_tags || !d_ids || !d_status))) return WH_ERR_PARAM;
+    WH_LOCK(c);
     if (stride < HhLayout(depth).total || n > 0x7fffffffull) return WH_ERR_PARAM;
     HIPCHK(c, hipSetDevice(c->device));
     int32_t rc;
@@ -995,6 +1055,7 @@ int32_t wh_hh_eval_and_check_batch_dev(wh_ctx *c, const uint8_t verify_key[16], 
 int32_t wh_hh_eval_and_check_batch(wh_ctx *c, const uint8_t verify_key[16], const uint8_t *keys, uint64_t stride, uint64_t n,
                                    uint32_t depth, uint8_t *tags, uint8_t *testing_ids, int32_t *status) {
     if (!c || !verify_key || (n && (!keys || !tags || !testing_ids || !status))) return WH_ERR_PARAM;
+    WH_LOCK(c);
     HIPCHK(c, hipSetDevice(c->device));
     int32_t rc;
     const uint64_t m = n ? n : 1;
@@ -1016,6 +1077,7 @@ int32_t wh_hh_eval_and_check_batch(wh_ctx *c, const uint8_t verify_key[16], cons
 
 int32_t wh_hh_buckets(wh_ctx *c, uint32_t *dat) {
     if (!c || !dat) return WH_ERR_PARAM;
+    WH_LOCK(c);
     if (!c->d_hh_dat_last) return WH_ERR_STATE;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(dat, c->d_hh_dat_last, c->hh_n_last * ((uint64_t)HH_BKT << c->hh_depth_last) * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1025,12 +1087,14 @@ int32_t wh_hh_buckets(wh_ctx *c, uint32_t *dat) {
 
 int32_t wh_hh_aggregate_dev(wh_ctx *c, const uint8_t *d_keep, uint32_t *d_acc, int32_t accumulate) {
     if (!c || !d_acc) return WH_ERR_PARAM;
+    WH_LOCK(c);
     if (!c->d_hh_dat_last) return WH_ERR_STATE;
     return hh_sum(c, c->d_hh_dat_last, d_keep, c->hh_n_last, (uint64_t)HH_BKT << c->hh_depth_last, d_acc, !accumulate);
 }
 
 int32_t wh_hh_aggregate(wh_ctx *c, const uint8_t *keep, uint32_t *acc) {
     if (!c || !acc) return WH_ERR_PARAM;
+    WH_LOCK(c);
     if (!c->d_hh_dat_last) return WH_ERR_STATE;
     HIPCHK(c, hipSetDevice(c->device));
     const uint64_t n = c->hh_n_last, words = (uint64_t)HH_BKT << c->hh_depth_last;
@@ -1050,12 +1114,14 @@ int32_t wh_hh_aggregate(wh_ctx *c, const uint8_t *keep, uint32_t *acc) {
 
 int32_t wh_ctx_set_profiling(wh_ctx *c, int32_t on) {
     if (!c) return WH_ERR_PARAM;
+    WH_LOCK(c);
     c->profiling = on != 0;
     return WH_OK;
 }
 
 int32_t wh_ctx_kernel_times(wh_ctx *c, double *ms, uint64_t *launches, int32_t reset) {
     if (!c || !ms || !launches) return WH_ERR_PARAM;
+    WH_LOCK(c);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (auto &e : c->evs) {
@@ -1073,6 +1139,7 @@ int32_t wh_ctx_kernel_times(wh_ctx *c, double *ms, uint64_t *launches, int32_t r
 
 int32_t wh_ctx_set_test_sampler_bound(wh_ctx *c, const uint8_t bound[16]) {
     if (!c) return WH_ERR_PARAM;
+    WH_LOCK(c);
     F128 b = F128{P_LO, P_HI};
     if (bound) {
         F128 v;
@@ -1085,45 +1152,56 @@ int32_t wh_ctx_set_test_sampler_bound(wh_ctx *c, const uint8_t bound[16]) {
 
 int32_t wh_test_f128_op(wh_ctx *c, int32_t op, const uint8_t *a, const uint8_t *b, uint8_t *out, uint64_t n) {
     if (!c || !a || !out || !n) return WH_ERR_PARAM;
+    WH_LOCK(c);
     HIPCHK(c, hipSetDevice(c->device));
-    F128 *da, *db, *dout;
-    HIPCHK(c, hipMalloc((void **)&da, 16 * n)); HIPCHK(c, hipMalloc((void **)&db, 16 * n)); HIPCHK(c, hipMalloc((void **)&dout, 16 * n));
-    HIPCHK(c, hipMemcpy(da, a, 16 * n, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(db, b ? b : a, 16 * n, hipMemcpyHostToDevice));
+    int32_t rc;
+    if ((rc = ensure(c, c->d_tmp_a, c->tmp_a_cap, 16 * n))) return rc;
+    if ((rc = ensure(c, c->d_tmp_b, c->tmp_b_cap, 16 * n))) return rc;
+    if ((rc = ensure(c, c->d_tmp_c, c->tmp_c_cap, 16 * n))) return rc;
+    F128 *da = reinterpret_cast<F128 *>(c->d_tmp_a), *db = reinterpret_cast<F128 *>(c->d_tmp_b), *dout = reinterpret_cast<F128 *>(c->d_tmp_c);
+    HIPCHK(c, hipMemcpyAsync(da, a, 16 * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(db, b ? b : a, 16 * n, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_test_f128, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, da, db, dout, (uint32_t)n, op);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, dout, 16 * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(out, dout, 16 * n, hipMemcpyDeviceToHost));
-    hipFree(da); hipFree(db); hipFree(dout);
     return WH_OK;
 }
 
 int32_t wh_test_f64_op(wh_ctx *c, int32_t op, const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t n) {
     if (!c || !a || !out || !n) return WH_ERR_PARAM;
+    WH_LOCK(c);
     HIPCHK(c, hipSetDevice(c->device));
-    uint64_t *da, *db, *dout;
-    HIPCHK(c, hipMalloc((void **)&da, 8 * n)); HIPCHK(c, hipMalloc((void **)&db, 8 * n)); HIPCHK(c, hipMalloc((void **)&dout, 8 * n));
-    HIPCHK(c, hipMemcpy(da, a, 8 * n, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(db, b ? b : a, 8 * n, hipMemcpyHostToDevice));
+    int32_t rc;
+    if ((rc = ensure(c, c->d_tmp_a, c->tmp_a_cap, 8 * n))) return rc;
+    if ((rc = ensure(c, c->d_tmp_b, c->tmp_b_cap, 8 * n))) return rc;
+    if ((rc = ensure(c, c->d_tmp_c, c->tmp_c_cap, 8 * n))) return rc;
+    uint64_t *da = reinterpret_cast<uint64_t *>(c->d_tmp_a), *db = reinterpret_cast<uint64_t *>(c->d_tmp_b), *dout = reinterpret_cast<uint64_t *>(c->d_tmp_c);
+    HIPCHK(c, hipMemcpyAsync(da, a, 8 * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(db, b ? b : a, 8 * n, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_test_f64, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, da, db, dout, (uint32_t)n, op);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, dout, 8 * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(out, dout, 8 * n, hipMemcpyDeviceToHost));
-    hipFree(da); hipFree(db); hipFree(dout);
     return WH_OK;
 }
 
 int32_t wh_test_xof_expand(wh_ctx *c, const uint8_t *seeds, uint64_t n, uint32_t alg_id, uint32_t usage, const uint8_t *binder,
                            uint32_t binder_len, uint32_t n_elems, uint8_t *out) {
     if (!c || !seeds || !out || !n || !n_elems) return WH_ERR_PARAM;
+    WH_LOCK(c);
     HIPCHK(c, hipSetDevice(c->device));
-    uint8_t *ds, *db, *dout;
-    HIPCHK(c, hipMalloc((void **)&ds, 16 * n)); HIPCHK(c, hipMalloc((void **)&db, binder_len + 16));
-    HIPCHK(c, hipMalloc((void **)&dout, 16ull * n_elems * n));
-    HIPCHK(c, hipMemcpy(ds, seeds, 16 * n, hipMemcpyHostToDevice));
-    if (binder_len) HIPCHK(c, hipMemcpy(db, binder, binder_len, hipMemcpyHostToDevice));
+    int32_t rc;
+    if ((rc = ensure(c, c->d_tmp_a, c->tmp_a_cap, 16 * n))) return rc;
+    if ((rc = ensure(c, c->d_tmp_b, c->tmp_b_cap, (uint64_t)binder_len + 16))) return rc;
+    if ((rc = ensure(c, c->d_tmp_c, c->tmp_c_cap, 16ull * n_elems * n))) return rc;
+    uint8_t *ds = c->d_tmp_a, *db = c->d_tmp_b, *dout = c->d_tmp_c;
+    HIPCHK(c, hipMemcpyAsync(ds, seeds, 16 * n, hipMemcpyHostToDevice, c->stream));
+    if (binder_len) HIPCHK(c, hipMemcpyAsync(db, binder, binder_len, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_test_xof, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, c->stream, ds, alg_id, usage, db, binder_len, n_elems, dout, (uint32_t)n, c->P.sampler_bound);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, dout, 16ull * n_elems * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(out, dout, 16ull * n_elems * n, hipMemcpyDeviceToHost));
-    hipFree(ds); hipFree(db); hipFree(dout);
     return WH_OK;
 }
 

@@ -74,7 +74,8 @@ __global__ void k_parse(Prio3Dev P, Workspace W, const uint8_t *blob, const uint
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint8_t *rep = blob + offsets[i];
-    uint64_t rep_len = offsets[i + 1] - offsets[i];
+    // a descending offset pair is an empty report (ST_ERR_SHORT), not a length of ~2^64
+    uint64_t rep_len = offsets[i + 1] >= offsets[i] ? offsets[i + 1] - offsets[i] : 0;
     RepDesc d;
     d.base = rep; d.meas = d.proof1 = d.proof2 = d.tail = d.jr_blind = d.seeds = nullptr; d.role = 0; d.hslot = 0;
     int32_t st = ST_OK;
@@ -310,7 +311,8 @@ __global__ void k_parse_base(Prio3Dev P, Workspace W, const uint8_t *blob, const
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint8_t *rep = blob + offsets[i];
-    uint64_t rep_len = offsets[i + 1] - offsets[i];
+    // a descending offset pair is an empty report (ST_ERR_SHORT), not a length of ~2^64
+    uint64_t rep_len = offsets[i + 1] >= offsets[i] ? offsets[i + 1] - offsets[i] : 0;
     RepDesc d;
     d.base = rep; d.meas = d.proof1 = d.proof2 = d.tail = d.jr_blind = d.seeds = nullptr; d.role = 0; d.hslot = 0;
     int32_t st = ST_OK;

@@ -6,8 +6,60 @@ server-batch-prio3/src/main.rs:282-335); what is reproduced here is its final me
 aggregates (main.rs:327-335, AggregateShare::merge vdaf.rs:658-676).  RCCL has no mod-p reduce op,
 so raw 16-byte limbs are all-gathered and summed on the GPU (wh_f128_sum_rows_dev).
 """
+import ctypes as C
+
+import numpy as np
 import torch
 import torch.distributed as dist
+
+from ._lib import lib, WhError
+
+COMM_ID_BYTES = 128
+
+
+# ---- the C-ABI combine (comm.hip): RCCL bound by the library itself, one context per GPU ----
+def comm_unique_id():
+    """ncclGetUniqueId through the library: rank 0 makes it, every rank passes it to comm_init."""
+    buf = np.zeros(COMM_ID_BYTES, np.uint8)
+    rc = lib.wh_comm_unique_id(buf.ctypes.data)
+    if rc:
+        raise WhError(rc, "wh_comm_unique_id (is RCCL present?)")
+    return buf.tobytes()
+
+
+def comm_init(obj, unique_id, rank, world):
+    """Bind a context (Prio3 or HeavyHitters instance) to rank `rank` of `world`; unique_id None = a lone GPU without RCCL."""
+    idb = None if unique_id is None else np.frombuffer(bytes(unique_id), np.uint8).copy()
+    obj._chk(lib.wh_comm_init(obj._ctx, None if idb is None else idb.ctypes.data, rank, world), "wh_comm_init")
+
+
+def comm_init_from_torch(obj, group=None):
+    """The same, with the unique id carried by an initialised torch.distributed group (any backend)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world == 1:
+        return comm_init(obj, None, 0, 1)
+    box = [comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    comm_init(obj, box[0], rank, world)
+
+
+def comm_rank(obj):
+    r, w = C.c_int32(), C.c_int32()
+    obj._chk(lib.wh_comm_rank(obj._ctx, C.byref(r), C.byref(w)), "wh_comm_rank")
+    return r.value, w.value
+
+
+def allgather_reduce_dev(obj, d_partial, d_agg, length=None):
+    """d_partial[len] Field128 (device pointer) -> d_agg[len] = sum over ranks mod p, asynchronous on the context stream."""
+    if length is None:
+        obj._chk(lib.wh_prio3_allgather_reduce_dev(obj._ctx, d_partial, d_agg), "wh_prio3_allgather_reduce_dev")
+    else:
+        obj._chk(lib.wh_f128_allgather_reduce_dev(obj._ctx, d_partial, length, d_agg), "wh_f128_allgather_reduce_dev")
+
+
+def hh_allreduce_u32_dev(obj, d_sketch, words):
+    obj._chk(lib.wh_hh_allreduce_u32_dev(obj._ctx, d_sketch, words), "wh_hh_allreduce_u32_dev")
 
 
 def shard_bounds(n, world_size, rank):

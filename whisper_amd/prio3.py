@@ -285,6 +285,21 @@ class Prio3:
         bad = np.frombuffer(b"".join(int(x).to_bytes(16, "little") for x in bad_ids), np.uint8) if len(bad_ids) else np.zeros(0, np.uint8)
         self._chk(lib.wh_keep_mask_dev(self._ctx, d_ids, n, bad.ctypes.data if len(bad) else None, len(bad) // 16, d_keep), "keep_mask_dev")
 
+    def allgather_reduce(self, keep=None):
+        """wh_prio3_allgather_reduce: the masked aggregate of the last batch on this GPU, combined over the ranks the context was
+        bound to (whisper_amd.dist.comm_init) -> bytes(output_len*16) on every rank."""
+        if keep is not None:
+            keep = np.ascontiguousarray(keep, dtype=np.uint8)
+        agg = np.zeros(16 * self.sizes.output_len, np.uint8)
+        self._chk(lib.wh_prio3_allgather_reduce(self._ctx, _ptr(keep), agg.ctypes.data), "allgather_reduce")
+        return agg
+
+    def lock(self):
+        self._chk(lib.wh_ctx_lock(self._ctx), "lock")
+
+    def unlock(self):
+        self._chk(lib.wh_ctx_unlock(self._ctx), "unlock")
+
     def aggregate_dev(self, d_keep, d_agg):
         self._chk(lib.wh_prio3_aggregate_dev(self._ctx, d_keep, d_agg), "aggregate_dev")
 
