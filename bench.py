@@ -49,7 +49,17 @@ HH_WORKLOADS = {
                       desc="heavy hitters, recovery threshold 0.001: 17 repetitions x 2048 buckets, 250 clients/GPU"),
 }
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-KECCAK_PEAK = 10.6e9         # Keccak-f[1600]/s, measured permutation-only ceiling of this kernel style on MI355X
+# Keccak-f[1600] on the vector ALUs.  A round is 122 full-rate instructions (v_bitop3_b32 / v_xor_b32: 2 cycles per wavefront
+# and SIMD, MI355X_MICROARCH.md "Per-instruction cycle constants") and 58 half-rate ones (v_alignbit_b32: 4 cycles), so a
+# wavefront-permutation costs 24 * (122 * 2 + 58 * 4) = 11 424 issue cycles and 1 024 SIMDs x 64 lanes at the 2.4 GHz maximum
+# clock give 13.8 G permutations/s: the issue-rate peak.  The measured ceiling of the same instruction stream with nothing else
+# in the kernel (tools/keccak_bench.hip, >= 4 wavefronts per SIMD, in-kernel clock 2.40 GHz, profiles/r2_keccak_bench.txt) is
+# 10.35 G/s = 15.2 k cycles per wavefront-permutation: the mix issues at 3.3 cycles per instruction, not 2.6.
+KECCAK_ISSUE_CYCLES = 24 * (122 * 2 + 58 * 4)
+MAX_CLOCK_HZ = 2.4e9
+KECCAK_PEAK = 1024 * 64 * MAX_CLOCK_HZ / KECCAK_ISSUE_CYCLES
+KECCAK_PEAK_MEASURED = 10.35e9
+K_MEAS_CLOCK_GHZ = 2.23      # in-kernel clock of k_meas (s_memtime / s_memrealtime, tools/meas_bench.hip, profiles/r2_meas_bench_probe.txt)
 
 
 def alg_bytes_per_report(s, role):
@@ -77,6 +87,9 @@ def main():
                     help="--unique distinct clients sharded on the CPU and tiled, instead of every report from a distinct client sharded on the GPU")
     ap.add_argument("--in-flight", type=int, default=1, help="contexts the steps alternate between (batches in flight)")
     ap.add_argument("--with-sort", action="store_true", help="also sort by testing id and build the keep mask from bad ids inside the step")
+    ap.add_argument("--host-buffers", choices=("pageable", "pinned"), default=None,
+                    help="time the host-buffer entry points instead (wh_prio3_prepare_batch + wh_prio3_aggregate): reports start in host "
+                         "memory, tags / ids / status / aggregate end there; PCIe inclusive")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -165,6 +178,9 @@ def main():
     keep = np.ones(n, np.uint8)
     keep[:: 1000] = 0                      # ~0.1 % of the clients flagged by the group test
     d_keep = torch.from_numpy(keep).to(dev)
+
+    if args.host_buffers:
+        return bench_host_buffers(args, vdaf, params, n, d_blob, d_off, keep, world, rank)
 
     # one lane = one context (stream, workspace) with its own outputs; --in-flight 2 alternates the steps between two
     # lanes, as a server does that starts on the next batch while the last one is still in its query / aggregation phase
@@ -289,6 +305,9 @@ def main():
         ex = (blk(16 * IL) + 2 * blk(16 * PL) + 3) if role == 1 else 0
         return jr + qr + hs + rlc + small + ex
     total_perms = n_lead * perms(0) + n_help * perms(1)
+    blk_ = lambda nbytes: -(-nbytes // 168)
+    meas_perms = (n_lead + n_help) * blk_(42 + 16 * s.input_len + 1) + n_help * (blk_(16 * s.input_len) + 1)   # k_meas alone
+    meas_ms = kernels["meas"]["ms_per_step"] if "meas" in kernels else None
 
     result = None
     if rank == 0:
@@ -305,17 +324,14 @@ def main():
                        "parallelism": f"reports sharded over {world} GPU(s); all-gather + mod-p reduce of partial aggregates",
                        "status_nonzero": n_bad_status, "client_gen_s": round(t_gen, 2),
                        "gpu_shard_clients_per_s": round(n / t_shard) if t_shard else None},
-            "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "avg_launch_ms": avg_ms, "alg_bytes_per_launch": bytes_per_launch,
-                         "note": "the verify kernels are integer-VALU bound (SHAKE128 + Field128), not HBM bound; see valu"},
+            "roofline": roofline_obj(dom, kernels, meas_perms, meas_ms, achieved, traffic, traffic_src, avg_ms, bytes_per_launch, launches),
             "valu": {"keccak_f1600_per_step": total_perms,
                      "keccak_f1600_per_s": total_perms * args.steps / elapsed,
                      "keccak_f1600_peak_per_s": KECCAK_PEAK,
+                     "keccak_f1600_peak_measured_per_s": KECCAK_PEAK_MEASURED,
                      "frac": total_perms * args.steps / elapsed / KECCAK_PEAK,
-                     "note": "peak = tools/keccak_bench.hip on this chip (state in VGPRs, >= 3 waves/SIMD, profiles/r1_keccak_bench.txt); "
-                             "a round is 122 v_bitop3/v_xor (full rate) + 58 v_alignbit (half rate); frac counts the whole step "
-                             "(query and aggregation included) against the permutation-only peak"},
+                     "frac_of_measured": total_perms * args.steps / elapsed / KECCAK_PEAK_MEASURED,
+                     "note": "whole step (query and aggregation included) against the permutation-only peaks of the roofline object"},
             "kernels": kernels,
         }
         if not args.no_cpu_baseline:
@@ -326,6 +342,77 @@ def main():
         dist.destroy_process_group()
     for ln in lanes:
         ln.vdaf.close()
+    return result
+
+
+def roofline_obj(dom, kernels, meas_perms, meas_ms, hbm_achieved, traffic, traffic_src, avg_ms, bytes_per_launch, launches):
+    """The dominant kernel against the resource that binds it.  k_meas (the measurement-share sponges) is bound by vector-ALU
+    issue: achieved = its Keccak-f[1600] per launch over its HIP-event duration, peak = the issue-rate figure at the maximum
+    clock; the measured ceiling of the bare instruction stream and the clock the kernel actually holds stand beside it.  Its
+    HBM figure (algorithmic bytes, PMC traffic) is kept in `hbm`."""
+    hbm = {"achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS, "traffic": traffic,
+           "traffic_source": traffic_src, "alg_bytes_per_launch": bytes_per_launch}
+    if dom != "meas" or not meas_ms:
+        return dict(hbm, bound="hbm", kernel="k_" + dom, avg_launch_ms=avg_ms)
+    ach = meas_perms / (meas_ms * 1e-3) / 1e9
+    return {"bound": "valu", "kernel": "k_meas", "achieved": ach, "peak": KECCAK_PEAK / 1e9, "unit": "G Keccak-f[1600]/s",
+            "frac": ach / (KECCAK_PEAK / 1e9), "traffic": traffic,
+            "peak_derivation": f"24 rounds x (122 full-rate x 2 + 58 half-rate x 4 cycles) = {KECCAK_ISSUE_CYCLES} issue cycles per wavefront-"
+                               f"permutation; 1024 SIMDs x 64 lanes x {MAX_CLOCK_HZ / 1e9} GHz",
+            "peak_measured": KECCAK_PEAK_MEASURED / 1e9, "frac_of_measured": ach / (KECCAK_PEAK_MEASURED / 1e9),
+            "peak_measured_source": "tools/keccak_bench.hip, profiles/r2_keccak_bench.txt: same round code, nothing else, >= 4 waves/SIMD, in-kernel clock 2.40 GHz",
+            "clock_ghz_in_kernel": K_MEAS_CLOCK_GHZ,
+            "frac_of_measured_at_kernel_clock": ach / (KECCAK_PEAK_MEASURED / 1e9 * K_MEAS_CLOCK_GHZ / 2.40),
+            "clock_source": "s_memtime / s_memrealtime stamps of a diagnostic build, tools/meas_bench.hip, profiles/r2_meas_bench_probe.txt",
+            "keccak_f1600_per_launch": meas_perms, "avg_launch_ms": meas_ms, "hbm": hbm}
+
+
+def bench_host_buffers(args, vdaf, params, n, d_blob, d_off, keep, world, rank):
+    """The call INTEGRATION.md binds for a Rust server holding Vec<Vec<u8>>: wh_prio3_prepare_batch (host blob in, tags / ids /
+    status out; chunked, double-buffered H2D under the verification) + wh_prio3_aggregate (host keep mask in, aggregate out)."""
+    import ctypes as C
+    s = params.sizes
+    off = d_off.cpu().numpy().astype(np.uint64)
+    nbytes = int(off[-1])
+    if args.host_buffers == "pinned":
+        p = C.c_void_p()
+        if W.lib.wh_host_alloc(nbytes + 1, C.byref(p)):
+            raise SystemExit("wh_host_alloc failed")
+        blob = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(nbytes + 1,))
+    else:
+        blob = np.empty(nbytes + 1, np.uint8)
+    step_b = 1 << 30
+    for lo in range(0, nbytes, step_b):                     # device -> host in pieces (no second 19 GB staging tensor)
+        hi = min(nbytes, lo + step_b)
+        blob[lo:hi] = d_blob[lo:hi].cpu().numpy()
+    del d_blob
+    torch.cuda.empty_cache()
+
+    def step():
+        tags, ids, status = vdaf.prepare_batch_host(VK, blob, off)
+        return tags, status, vdaf.aggregate(keep)
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tags, status, agg = step()
+    elapsed = time.perf_counter() - t0
+    result = {
+        "metric": "verified+aggregated client reports/sec (node), Prio3 SumVec, host buffers in and out (PCIe inclusive)",
+        "value": n * args.steps / elapsed, "unit": "reports/s", "n_gpus": 1, "steps": args.steps, "warmup": max(1, args.warmup),
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u128 (Field128 mod p) + u64 (Keccak lanes)", "data": "synthetic",
+        "config": {"workload": WORKLOADS[args.workload]["desc"], "reports_per_gpu": n, "inputs": f"host memory ({args.host_buffers})",
+                   "entry_points": "wh_prio3_prepare_batch + wh_prio3_aggregate", "bytes_in_per_step": nbytes,
+                   "chunk_mb": int(os.environ.get("WH_HOST_CHUNK_MB", "2048")), "status_nonzero": int((status != 0).sum())},
+        "pcie": {"h2d_gb_per_s": nbytes * args.steps / elapsed / 1e9, "note": "report bytes over the whole step time (verification of chunk k runs under the copy of chunk k + 1)"},
+    }
+    if rank == 0:
+        print(json.dumps(result))
+    vdaf.close()
+    if args.host_buffers == "pinned":
+        W.lib.wh_host_free(p)
     return result
 
 

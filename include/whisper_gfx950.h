@@ -106,10 +106,17 @@ int32_t wh_prio3_prepare_batch_dev(wh_ctx *ctx, const uint8_t verify_key[16], co
                                    const uint64_t *d_offsets, uint64_t n, uint8_t *d_tags,
                                    uint8_t *d_testing_ids, int32_t *d_status);
 /* Same with HOST buffers (what a Rust caller holding Vec<Vec<u8>> would use); copies in and out
- * and synchronises. */
+ * and synchronises.  The batch crosses PCIe in chunks (2 GiB; WH_HOST_CHUNK_MB) through two device buffers, the copy of
+ * chunk k+1 under the verification of chunk k.  Pageable input is staged through pinned context memory by several host
+ * threads (WH_HOST_COPY_THREADS, at most 8); input in pinned memory (wh_host_alloc, hipHostRegister) goes straight to the
+ * DMA engine. */
 int32_t wh_prio3_prepare_batch(wh_ctx *ctx, const uint8_t verify_key[16], const uint8_t *blob,
                                const uint64_t *offsets, uint64_t n, uint8_t *tags, uint8_t *testing_ids,
                                int32_t *status);
+/* No counterpart in the reference (its reports arrive in Vec<u8>s from tokio sockets, bridge/src/client_server.rs): pinned host
+ * memory for a receive path that wants the DMA engine to read the reports where the sockets put them. */
+int32_t wh_host_alloc(uint64_t bytes, void **out);
+int32_t wh_host_free(void *p);
 /* replaces: Prio3::prepare_batched's second return value (OutputShare).  Copies the n*output_len
  * out-share elements of the last batch to the host.  WH_ERR_STATE unless the last call that used the
  * context's workspace was a prepare call or wh_flp_query_batch (wh_client_shard_many_gpu leaves nothing). */

@@ -205,3 +205,54 @@ def test_combine_behind_the_c_abi_with_one_rank(through_rccl):
         assert np.array_equal(d_sk.cpu().numpy().view(np.uint32), sk)
     finally:
         h.close()
+
+
+def test_host_buffer_path_in_chunks_pageable_and_pinned(monkeypatch):
+    """wh_prio3_prepare_batch moves the batch in chunks through two device buffers (copy of chunk k + 1 under the verification of
+    chunk k): with 1 MiB chunks a 300-report batch takes a dozen of them.  Same tags, ids, status and aggregate as one chunk, for
+    pageable and for pinned (wh_host_alloc) input, with malformed reports at chunk seams; a sample against the oracle."""
+    import ctypes as C
+    cfg = (W.SUMVEC, 16, 128, 64)
+    p = W.Prio3Params(*cfg)
+    n = 300
+    lr, hr, _ = make_reports(p, n, seed=34)
+    alice, _ = server_views(lr, hr)
+    alice[17] = alice[17][:100]                       # short
+    alice[150] = alice[150][:48] + b"\x07" + alice[150][49:]   # bad aggregator id
+    alice[299] = b""                                  # empty, last
+    blob, off = blob_of(alice)
+    blob = np.concatenate([blob, np.zeros(1, np.uint8)])
+    keep = np.ones(n, np.uint8)
+    keep[::7] = 0
+    vdaf = W.Prio3(p)
+    try:
+        monkeypatch.delenv("WH_HOST_CHUNK_MB", raising=False)
+        ref = vdaf.prepare_batch_host(VK, blob, off)
+        ref_agg = vdaf.aggregate(keep)
+        assert ref[2][17] == WH_ERR_SHORT and ref[2][150] == -4 and ref[2][299] == WH_ERR_SHORT
+        assert int((ref[2] != 0).sum()) == 3
+        sample = list(range(0, 40))
+        sblob, soff = blob_of([alice[i] for i in sample])
+        o_tags, o_ids, o_status, _ = O.prio3_prepare_batch(O.params(*cfg), VK, sblob, soff, nthreads=4)
+        assert np.array_equal(ref[0][sample], o_tags) and np.array_equal(ref[1][sample], o_ids) and np.array_equal(ref[2][sample], o_status)
+        monkeypatch.setenv("WH_HOST_CHUNK_MB", "1")
+        got = vdaf.prepare_batch_host(VK, blob, off)
+        assert all(np.array_equal(a, b) for a, b in zip(got, ref))
+        assert np.array_equal(vdaf.aggregate(keep), ref_agg)
+        # pinned input: no staging copy
+        ptr = C.c_void_p()
+        assert W.lib.wh_host_alloc(blob.size, C.byref(ptr)) == 0
+        try:
+            pinned = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(blob.size,))
+            pinned[:] = blob
+            got = vdaf.prepare_batch_host(VK, pinned, off)
+            assert all(np.array_equal(a, b) for a, b in zip(got, ref))
+            assert np.array_equal(vdaf.aggregate(keep), ref_agg)
+            monkeypatch.setenv("WH_HOST_COPY_THREADS", "1")
+            got = vdaf.prepare_batch_host(VK, blob, off)       # pageable again, one copy thread
+            assert all(np.array_equal(a, b) for a, b in zip(got, ref))
+        finally:
+            del pinned
+            assert W.lib.wh_host_free(ptr) == 0
+    finally:
+        vdaf.close()

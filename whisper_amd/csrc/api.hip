@@ -8,6 +8,7 @@
 #include <vector>
 #include <algorithm>
 #include <mutex>
+#include <thread>
 #include "host_math.hpp"
 #include "aes_host.hpp"
 #include "hh_dev.hpp"
@@ -38,6 +39,10 @@ struct wh_ctx {
     // expansion, public-parts hash / RLC / testing id): they slip in beside k_meas
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // host-buffer entry points: copy stream, "chunk b has arrived" / "chunk b has been verified" events, pinned staging
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    uint8_t *h_stage = nullptr; uint64_t h_stage_cap = 0;
     wh_prio3_params params{};
     HostSizes z{};
     Prio3Dev P{};
@@ -300,6 +305,10 @@ int32_t wh_ctx_create(int32_t device_id, const wh_prio3_params *params, wh_ctx *
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(WH_ERR_HIP);
     if (hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) return fail(WH_ERR_HIP);
     if (hipEventCreateWithFlags(&c->ev_bad, hipEventDisableTiming) != hipSuccess) return fail(WH_ERR_HIP);
+    if (hipStreamCreate(&c->copy_stream) != hipSuccess) return fail(WH_ERR_HIP);
+    for (int b = 0; b < 2; b++)
+        if (hipEventCreateWithFlags(&c->ev_h2d[b], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_done[b], hipEventDisableTiming) != hipSuccess) return fail(WH_ERR_HIP);
     c->err.reserve(256);                 // later error texts need no host allocation either
     if ((rc = scratch_of_device(c))) return fail(rc);
 
@@ -346,6 +355,9 @@ void wh_ctx_destroy(wh_ctx *c) {
                     c->d_hh_ids, c->d_hh_status, c->d_hh_keep, c->d_hh_acc, c->d_sort_tmp, c->d_sort_hist, c->d_bad_ids};
     for (void *p : ptrs) if (p) hipFree(p);
     if (c->h_bad) hipHostFree(c->h_bad);
+    if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
+    for (int b = 0; b < 2; b++) { if (c->ev_h2d[b]) hipEventDestroy(c->ev_h2d[b]); if (c->ev_done[b]) hipEventDestroy(c->ev_done[b]); }
+    if (c->h_stage) hipHostFree(c->h_stage);
     for (auto &e : c->evs) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
@@ -369,11 +381,13 @@ int32_t wh_ctx_synchronize(wh_ctx *c) {
     return WH_OK;
 }
 
-int32_t wh_prio3_prepare_batch_dev(wh_ctx *c, const uint8_t verify_key[16], const uint8_t *d_blob,
-                                   const uint64_t *d_offsets, uint64_t n, uint8_t *d_tags, uint8_t *d_ids,
-                                   int32_t *d_status) {
-    if (!c || !verify_key || (n && (!d_blob || !d_offsets || !d_tags || !d_ids || !d_status))) return WH_ERR_PARAM;
-    WH_LOCK(c);
+// One batched verification in two parts, so that the host-buffer entry point can feed it chunk by chunk while the next chunk
+// is still crossing PCIe: prepare_begin sizes the context for n reports (all allocations happen here), prepare_range enqueues
+// the kernel sequence for reports [base, base + nb) whose encodings sit at d_blob + d_off[0 .. nb].
+struct PrepPlan { uint64_t vk0 = 0, vk1 = 0; QueryLaunch q{}; };
+
+static int32_t prepare_begin(wh_ctx *c, const uint8_t verify_key[16], uint64_t n, uint64_t max_range, const int32_t *d_status,
+                             PrepPlan &pl) {
     if (n > 0xfffffff0ull || c->params.num_aggregators != 2) return WH_ERR_PARAM;
     HIPCHK(c, hipSetDevice(c->device));
     const HostSizes &z = c->z;
@@ -381,7 +395,7 @@ int32_t wh_prio3_prepare_batch_dev(wh_ctx *c, const uint8_t verify_key[16], cons
     c->P.mode = 0; c->P.ver_stride = 0;
     c->P.half = f_inv(f_small(2));
     // allocations first (none inside the launch sequence once the context is warm)
-    if ((rc = alloc_workspace(c, pick_cap(c, n)))) return rc;
+    if ((rc = alloc_workspace(c, pick_cap(c, max_range)))) return rc;
     if ((rc = ensure(c, c->d_out_shares, c->out_cap, (n ? n : 1) * (uint64_t)z.output_len))) return rc;
     if (d_status != c->d_status_own && (rc = ensure(c, c->d_status_keep, c->status_keep_cap, n ? n : 1))) return rc;
     c->producer = wh_ctx::NONE; c->n_last = 0;           // until this batch is enqueued completely
@@ -393,18 +407,26 @@ int32_t wh_prio3_prepare_batch_dev(wh_ctx *c, const uint8_t verify_key[16], cons
         memcpy(c->d_aes_key, verify_key, 16);
         c->aes_valid = true;
     }
-    uint64_t vk0, vk1;
-    memcpy(&vk0, verify_key, 8); memcpy(&vk1, verify_key + 8, 8);
-    const QueryLaunch q = query_launch(c, false);
-    if (!q.fn) { c->err = "circuit has too many gadget calls for the query kernel's LDS rows"; return WH_ERR_UNSUPPORTED; }
+    memcpy(&pl.vk0, verify_key, 8); memcpy(&pl.vk1, verify_key + 8, 8);
+    pl.q = query_launch(c, false);
+    if (!pl.q.fn) { c->err = "circuit has too many gadget calls for the query kernel's LDS rows"; return WH_ERR_UNSUPPORTED; }
+    return WH_OK;
+}
+
+// d_tags / d_ids / d_status are the whole batch's arrays; the range writes its slice [base, base + nb)
+static int32_t prepare_range(wh_ctx *c, const PrepPlan &pl, const uint8_t *d_blob, const uint64_t *d_off, uint64_t nr, uint64_t base0,
+                             uint8_t *d_tags, uint8_t *d_ids, int32_t *d_status) {
+    const HostSizes &z = c->z;
+    const QueryLaunch &q = pl.q;
     uint8_t *d_out = reinterpret_cast<uint8_t *>(c->d_out_shares);
-    for (uint64_t base = 0; base < n; base += c->cap) {
-        const uint32_t nb = (uint32_t)((n - base < c->cap) ? n - base : c->cap);
+    for (uint64_t r = 0; r < nr; r += c->cap) {
+        const uint64_t base = base0 + r;
+        const uint32_t nb = (uint32_t)((nr - r < c->cap) ? nr - r : c->cap);
         const uint32_t npad = (nb + 255) / 256 * 256;
         uint8_t *tags_b = d_tags + 16 * base, *out_b = d_out + 16 * base * z.output_len;
         HIPCHK(c, hipMemsetAsync(c->W.counters, 0, 64, c->stream));
         { KTimer t_(c, WH_K_PARSE);
-        hipLaunchKernelGGL(k_parse, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, d_blob, d_offsets + base, nb,
+        hipLaunchKernelGGL(k_parse, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, d_blob, d_off + r, nb,
                            d_status + base, tags_b, out_b); }
         // side stream: the Helpers' proof shares (short, independent of k_meas, and harmless beside it:
         // it runs in the wave slots k_meas leaves; the hash kernel beside k_meas is not)
@@ -424,16 +446,33 @@ int32_t wh_prio3_prepare_batch_dev(wh_ctx *c, const uint8_t verify_key[16], cons
         launch_meas(c->P, c->W, 1, npad, d_status + base, c->stream);
         if (side) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         { KTimer t_(c, WH_K_HASH);
-        hipLaunchKernelGGL(k_hash, dim3(2 * npad / 256), dim3(256), 0, c->stream, c->P, c->W, npad, 2u, vk0, vk1,
+        hipLaunchKernelGGL(k_hash, dim3(2 * npad / 256), dim3(256), 0, c->stream, c->P, c->W, npad, 2u, pl.vk0, pl.vk1,
                            c->d_aes, d_ids + 16 * base, d_status + base); }
         { KTimer t_(c, WH_K_QUERY);
         hipLaunchKernelGGL(q.fn, dim3(q.polyeval ? (nb + 3) / 4 : nb), dim3(64 * q.waves), q.lds, c->stream, c->P, c->W,
                            tags_b, out_b, d_status + base); }
         HIPCHK(c, hipGetLastError());
     }
+    return WH_OK;
+}
+
+static int32_t prepare_end(wh_ctx *c, const int32_t *d_status, uint64_t n) {
+    int32_t rc;
     if ((rc = remember_status(c, d_status, n))) return rc;
     c->n_last = n; c->producer = wh_ctx::PREPARE_BATCH;
     return WH_OK;
+}
+
+int32_t wh_prio3_prepare_batch_dev(wh_ctx *c, const uint8_t verify_key[16], const uint8_t *d_blob,
+                                   const uint64_t *d_offsets, uint64_t n, uint8_t *d_tags, uint8_t *d_ids,
+                                   int32_t *d_status) {
+    if (!c || !verify_key || (n && (!d_blob || !d_offsets || !d_tags || !d_ids || !d_status))) return WH_ERR_PARAM;
+    WH_LOCK(c);
+    PrepPlan pl;
+    int32_t rc;
+    if ((rc = prepare_begin(c, verify_key, n, n, d_status, pl))) return rc;
+    if ((rc = prepare_range(c, pl, d_blob, d_offsets, n, 0, d_tags, d_ids, d_status))) return rc;
+    return prepare_end(c, d_status, n);
 }
 
 int32_t wh_prio3_prepare_init_batch_dev(wh_ctx *c, const uint8_t verify_key[16], const uint8_t *d_blob,
@@ -837,6 +876,38 @@ int32_t wh_flp_decide_batch(wh_ctx *c, const uint8_t *verifier, uint64_t n, int3
     return WH_OK;
 }
 
+// pinned host memory for callers that receive reports straight into it (sockets -> pinned buffer -> DMA): the host-buffer
+// entry points then skip their staging copy
+int32_t wh_host_alloc(uint64_t bytes, void **out) {
+    if (!out || !bytes) return WH_ERR_PARAM;
+    *out = nullptr;
+    return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? WH_OK : WH_ERR_HIP;
+}
+int32_t wh_host_free(void *p) { return !p || hipHostFree(p) == hipSuccess ? WH_OK : WH_ERR_HIP; }
+
+static bool is_pinned_host(const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+// copy with several host threads: one core moves ~10 GB/s, PCIe Gen5 x16 takes ~55
+static void parallel_copy(uint8_t *dst, const uint8_t *src, uint64_t bytes, unsigned threads) {
+    if (bytes < (8u << 20) || threads < 2) { memcpy(dst, src, bytes); return; }
+    std::vector<std::thread> th;
+    const uint64_t per = (bytes / threads + 4095) & ~4095ull;
+    for (unsigned t = 0; t < threads; t++) {
+        const uint64_t lo = (uint64_t)t * per, hi = lo + per < bytes ? lo + per : bytes;
+        if (lo >= hi) break;
+        th.emplace_back([=] { memcpy(dst + lo, src + lo, hi - lo); });
+    }
+    for (auto &x : th) x.join();
+}
+
+// Host buffers in, host buffers out: the batch crosses PCIe in chunks (default 2 GiB, WH_HOST_CHUNK_MB) through two device
+// buffers, the copy of chunk k + 1 (copy stream) under the verification of chunk k (context stream).  Pageable input is
+// first moved into two pinned staging buffers by several host threads (that copy of chunk k + 1 runs under the DMA of chunk
+// k); input that already is pinned (wh_host_alloc, hipHostRegister) goes straight to the DMA engine.
 int32_t wh_prio3_prepare_batch(wh_ctx *c, const uint8_t verify_key[16], const uint8_t *blob, const uint64_t *offsets,
                                uint64_t n, uint8_t *tags, uint8_t *ids, int32_t *status) {
     if (!c || !verify_key || (n && (!blob || !offsets || !tags || !ids || !status))) return WH_ERR_PARAM;
@@ -845,19 +916,64 @@ int32_t wh_prio3_prepare_batch(wh_ctx *c, const uint8_t verify_key[16], const ui
     if (n == 0) { c->n_last = 0; c->d_status_last = nullptr; c->producer = wh_ctx::PREPARE_BATCH; return WH_OK; }
     for (uint64_t i = 0; i < n; i++) if (offsets[i + 1] < offsets[i]) return WH_ERR_PARAM;
     int32_t rc;
-    const uint64_t base0 = offsets[0], bytes = offsets[n] - base0;
-    if ((rc = ensure(c, c->d_blob, c->blob_cap, bytes + 64))) return rc;
-    if ((rc = ensure(c, c->d_offsets, c->off_cap, n + 1))) return rc;
+    uint64_t chunk_bytes = 2048ull << 20;
+    if (const char *e = getenv("WH_HOST_CHUNK_MB")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 1) chunk_bytes = v << 20; }
+    // chunk boundaries: whole reports, at most chunk_bytes each (a single larger report is a chunk of its own)
+    std::vector<uint64_t> first{0};
+    uint64_t max_bytes = 0, max_reports = 0;
+    for (uint64_t i = 0; i < n;) {
+        uint64_t j = i + 1;
+        while (j < n && offsets[j + 1] - offsets[i] <= chunk_bytes) j++;
+        max_bytes = std::max(max_bytes, offsets[j] - offsets[i]);
+        max_reports = std::max(max_reports, j - i);
+        first.push_back(j);
+        i = j;
+    }
+    const uint64_t nchunks = first.size() - 1;
+    const bool pinned_in = is_pinned_host(blob);
+    const uint64_t nbuf = nchunks > 1 ? 2 : 1;
+    const uint64_t dev_stride = (max_bytes + 64 + 255) & ~255ull, off_stride = max_reports + 1;
+    if ((rc = ensure(c, c->d_blob, c->blob_cap, nbuf * dev_stride))) return rc;
+    if ((rc = ensure(c, c->d_offsets, c->off_cap, nbuf * off_stride))) return rc;
     if ((rc = ensure(c, c->d_tags, c->tags_cap, 16 * n))) return rc;
     if ((rc = ensure(c, c->d_ids, c->ids_cap, 16 * n))) return rc;
     if ((rc = ensure(c, c->d_status_own, c->status_cap, n))) return rc;
-    std::vector<uint64_t> rel(n + 1);
-    for (uint64_t i = 0; i <= n; i++) rel[i] = offsets[i] - base0;
-    HIPCHK(c, hipMemcpyAsync(c->d_blob, blob + base0, bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_offsets, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if ((rc = wh_prio3_prepare_batch_dev(c, verify_key, c->d_blob, c->d_offsets, n, c->d_tags, c->d_ids, c->d_status_own)))
-        return rc;
+    // pinned staging: the relative offsets of both chunks in flight, and (pageable input only) their bytes
+    const uint64_t stage_bytes = nbuf * off_stride * 8 + (pinned_in ? 0 : nbuf * dev_stride);
+    if (stage_bytes > c->h_stage_cap) {
+        if (c->h_stage) HIPCHK(c, hipHostFree(c->h_stage));
+        c->h_stage = nullptr; c->h_stage_cap = 0;
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_stage), stage_bytes, hipHostMallocDefault));
+        c->h_stage_cap = stage_bytes;
+    }
+    uint64_t *h_off = reinterpret_cast<uint64_t *>(c->h_stage);
+    uint8_t *h_bytes = c->h_stage + nbuf * off_stride * 8;
+    PrepPlan pl;
+    if ((rc = prepare_begin(c, verify_key, n, max_reports, c->d_status_own, pl))) return rc;
+    unsigned threads = std::thread::hardware_concurrency();
+    if (const char *e = getenv("WH_HOST_COPY_THREADS")) threads = (unsigned)strtoul(e, nullptr, 10);
+    threads = threads < 1 ? 1 : (threads > 8 ? 8 : threads);
+    bool used[2] = {false, false};
+    for (uint64_t k = 0; k < nchunks; k++) {
+        const uint64_t b = k % nbuf, lo = first[k], hi = first[k + 1], bytes = offsets[hi] - offsets[lo];
+        // the pinned staging of this buffer was last read by the copy of chunk k - 2
+        if (used[b]) HIPCHK(c, hipEventSynchronize(c->ev_h2d[b]));
+        uint64_t *rel = h_off + b * off_stride;
+        for (uint64_t i = lo; i <= hi; i++) rel[i - lo] = offsets[i] - offsets[lo];
+        const uint8_t *src = blob + offsets[lo];
+        if (!pinned_in) { parallel_copy(h_bytes + b * dev_stride, src, bytes, threads); src = h_bytes + b * dev_stride; }
+        // the device buffer was last read by the verification of chunk k - 2
+        if (used[b]) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_done[b], 0));
+        HIPCHK(c, hipMemcpyAsync(c->d_blob + b * dev_stride, src, bytes, hipMemcpyHostToDevice, c->copy_stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_offsets + b * off_stride, rel, (hi - lo + 1) * 8, hipMemcpyHostToDevice, c->copy_stream));
+        HIPCHK(c, hipEventRecord(c->ev_h2d[b], c->copy_stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_h2d[b], 0));
+        if ((rc = prepare_range(c, pl, c->d_blob + b * dev_stride, c->d_offsets + b * off_stride, hi - lo, lo, c->d_tags, c->d_ids,
+                                c->d_status_own))) return rc;
+        HIPCHK(c, hipEventRecord(c->ev_done[b], c->stream));
+        used[b] = true;
+    }
+    if ((rc = prepare_end(c, c->d_status_own, n))) return rc;
     HIPCHK(c, hipMemcpyAsync(tags, c->d_tags, 16 * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(ids, c->d_ids, 16 * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(status, c->d_status_own, 4 * n, hipMemcpyDeviceToHost, c->stream));
