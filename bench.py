@@ -445,7 +445,7 @@ def bench_hh(args, rank, local_rank, world, dev, backend):
     if wh_comm:
         comm_init_from_torch(h)
     d_keys = torch.from_numpy(keys).to(dev)
-    d_dat = torch.empty((n, N, 258), dtype=torch.int32, device=dev)
+    d_dat = torch.empty((n, N, 258), dtype=torch.int32, device=dev) if os.environ.get("WH_BENCH_HH_MATERIALIZE") else None
     d_tags = torch.zeros((n, 64), dtype=torch.uint8, device=dev)
     d_ids = torch.zeros((n, 16), dtype=torch.uint8, device=dev)
     d_status = torch.zeros(n, dtype=torch.int32, device=dev)
@@ -456,11 +456,20 @@ def bench_hh(args, rank, local_rank, world, dev, backend):
     words = N * 258
     torch.cuda.synchronize()
 
+    bad_index = np.flatnonzero(keep == 0).astype(np.uint64)
+    fused = not os.environ.get("WH_BENCH_HH_MATERIALIZE")
+
     def step():
-        h.eval_and_check_dev(VK, d_keys.data_ptr(), ln, n, d_dat.data_ptr(), d_tags.data_ptr(), d_ids.data_ptr(), d_status.data_ptr())
-        for r in range(reps):                            # one sketch per repetition (aggregate_hhs)
-            h.bucket_sum_u32_dev(d_dat.data_ptr() + 4 * r * clients * words, d_keep.data_ptr() + r * clients, clients, words,
-                                 d_acc.data_ptr() + 4 * r * words)
+        if fused:
+            # the sum of every key chain's buckets inside the expansion (one sketch per repetition), then the key chains the group
+            # test rejected are expanded once more and taken out again: nothing is materialised
+            h.eval_and_sketch_dev(VK, d_keys.data_ptr(), ln, n, clients, d_acc.data_ptr(), d_tags.data_ptr(), d_ids.data_ptr(), d_status.data_ptr())
+            h.sketch_subtract_dev(VK, d_keys.data_ptr(), ln, bad_index, clients, d_acc.data_ptr())
+        else:
+            h.eval_and_check_dev(VK, d_keys.data_ptr(), ln, n, d_dat.data_ptr(), d_tags.data_ptr(), d_ids.data_ptr(), d_status.data_ptr())
+            for r in range(reps):                            # one sketch per repetition (aggregate_hhs)
+                h.bucket_sum_u32_dev(d_dat.data_ptr() + 4 * r * clients * words, d_keep.data_ptr() + r * clients, clients, words,
+                                     d_acc.data_ptr() + 4 * r * words)
         if wh_comm:
             hh_allreduce_u32_dev(h, d_acc.data_ptr(), reps * words)
         elif world > 1:
@@ -493,13 +502,16 @@ def bench_hh(args, rank, local_rank, world, dev, backend):
     result = None
     if rank == 0:
         kernels = {k: {"ms_per_step": ms / args.steps, "launches_per_step": cnt / args.steps} for k, (ms, cnt) in ktimes.items() if cnt}
-        main_ms = kernels["hh_main"]["ms_per_step"] / kernels["hh_main"]["launches_per_step"]
-        # k_hh_main per key chain: the key chain read, the bucket vectors and the corrected leaf hashes written
-        main_bytes = n * (ln + 4 * words + 64 * N + 4 * 258 + 20)
+        main_ms = kernels["hh_main"]["ms_per_step"]          # all launches of the step: the batch, and the rejected key chains again
+        # k_hh_main per key chain: the key chain read, the corrected leaf hashes written; the bucket vectors are either
+        # written (materialised path) or added into the L2-resident sketches (fused path: no HBM bytes per key chain)
+        main_bytes = n * (ln + (0 if fused else 4 * words) + 64 * N + 4 * 258 + 20) + (len(bad_index) * ln if fused else 0)
         # AES blocks the algorithm needs per key chain: tree, leaf hashes, 65 counters per leaf, proof chain,
         # 14 per support key, testing id; in k_hh_main: all but the chain and the support keys
         aes_all = 2 * (N - 1) + 2 * N + 65 * N + 4 * N + 257 * 14 + 1
         aes_main = 2 * (N - 1) + 2 * N + 65 * N + 1
+        aes_sub = 2 * (N - 1) + 65 * N + 1                    # a subtract launch skips the leaf hashes
+        main_blocks = n * aes_main + (len(bad_index) * aes_sub if fused else 0)
         # two bounds of the table AES, both from tools/aes_microbench.hip: instruction issue (per block and wavefront
         # 160 x (v_perm 4.2 + ds_read 2.6) + 16 x 2.6 + 80 x 2.3 cycles on one of 4 SIMDs) and the LDS itself
         # (176 ds_read_b32 per block, a CU serves 32 lanes per clock); the lower one binds
@@ -525,14 +537,18 @@ def bench_hh(args, rank, local_rank, world, dev, backend):
                        "key_chains_per_step_per_gpu": n, "key_chain_bytes": ln, "distinct_key_chains_tiled": K,
                        "inputs": "resident in HBM", "status_nonzero": n_bad_status, "client_gen_s": round(t_gen, 2),
                        "parallelism": f"key chains sharded over {world} GPU(s); integer all-reduce of the sketches"},
-            "roofline": {"bound": "hbm", "kernel": "k_hh_main", "achieved": main_bytes / (main_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": main_bytes / (main_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": traffic_src,
-                         "avg_launch_ms": main_ms, "alg_bytes_per_launch": main_bytes,
-                         "note": "table-driven AES is bound by instruction issue, not by HBM; see valu"},
+            "roofline": {"bound": "lds", "kernel": "k_hh_main", "achieved": main_blocks / (main_ms * 1e-3) / 1e9, "peak": aes_peak / 1e9,
+                         "unit": "G AES-128 blocks/s", "frac": main_blocks / (main_ms * 1e-3) / aes_peak, "traffic": traffic,
+                         "peak_derivation": "table AES: 176 ds_read_b32 per block at 32 lanes/clk/CU = 111.7 G blocks/s at 2.4 GHz; instruction "
+                                            "issue (VALU and LDS instructions of a SIMD do not overlap) 119.7 G blocks/s; the lower binds",
+                         "ms_per_step_all_launches": main_ms, "aes_blocks_per_step": main_blocks,
+                         "sketch_sum": "fused into the expansion (atomic adds into per-XCD partial sketches)" if fused else "materialised, then k_hh_sum_u32",
+                         "hbm": {"achieved": main_bytes / (main_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": main_bytes / (main_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                                 "alg_bytes_per_step": main_bytes}},
             "valu": {"aes_blocks_per_step": n * aes_all, "aes_blocks_per_s": n * aes_all * args.steps / elapsed * world,
-                     "k_hh_main_aes_blocks_per_s": n * aes_main / (main_ms * 1e-3), "aes_bound_blocks_per_s": aes_peak,
-                     "frac": n * aes_main / (main_ms * 1e-3) / aes_peak,
+                     "k_hh_main_aes_blocks_per_s": main_blocks / (main_ms * 1e-3), "aes_bound_blocks_per_s": aes_peak,
+                     "frac": main_blocks / (main_ms * 1e-3) / aes_peak,
                      "note": "bound = the lower of the LDS rate (176 table reads per block at 32 lanes/clk/CU: 111.7 G blocks/s) and "
                              "instruction issue (160 x (v_perm_b32 4.2 + ds_read_b32 2.6) + 16 x 2.6 + 80 x 2.3 cycles per block and "
                              "wavefront; VALU and LDS instructions of a SIMD do not overlap: 119.7 G blocks/s) "

@@ -237,6 +237,20 @@ uint64_t wh_hh_key_chain_len(uint32_t depth);
 int32_t wh_hh_ctx_create(int32_t device_id, wh_ctx **out);
 int32_t wh_hh_eval_and_check_batch_dev(wh_ctx *ctx, const uint8_t verify_key[16], const uint8_t *d_keys, uint64_t stride, uint64_t n,
                                        uint32_t depth, uint32_t *d_dat, uint8_t *d_tags, uint8_t *d_testing_ids, int32_t *d_status);
+/* replaces: the same expansion TOGETHER with aggregate_hhs' sum (server-hh/src/main.rs:72-104; Bucket::add, hhcore/src/bucket.rs:
+ * 48-55): the caller holds no Vec<Bucket<u32>> (528 KB per key chain at 512 buckets); a sub-batch of bucket vectors lives in
+ * context scratch and is summed into the sketches on a side stream under the proof-string kernels of the same sub-batch.
+ * Key chain i goes into sketch i / group_size (one sketch per repetition when the batch is
+ * repetition-major with group_size clients each): d_sketch[ceil(n / group_size)][2^depth * 258] u32, overwritten unless
+ * `accumulate` (the streaming server's CountSketch::insert, main.rs:192-197).  ALL well-formed key chains are summed, the
+ * group test has not run yet; afterwards wh_hh_sketch_subtract_dev takes the rejected ones out again ("sum all, subtract the
+ * bad": exact in Z/2^32).  Malformed key chains (status != 0) contribute nothing in either call.
+ * bad_index: n_bad indices into d_keys (HOST memory), the key chains whose testing ids the group test returned. */
+int32_t wh_hh_eval_and_sketch_batch_dev(wh_ctx *ctx, const uint8_t verify_key[16], const uint8_t *d_keys, uint64_t stride, uint64_t n,
+                                        uint32_t depth, uint64_t group_size, uint32_t *d_sketch, int32_t accumulate, uint8_t *d_tags,
+                                        uint8_t *d_testing_ids, int32_t *d_status);
+int32_t wh_hh_sketch_subtract_dev(wh_ctx *ctx, const uint8_t verify_key[16], const uint8_t *d_keys, uint64_t stride, uint32_t depth,
+                                  const uint64_t *bad_index, uint64_t n_bad, uint64_t group_size, uint32_t *d_sketch);
 /* Same with HOST buffers; the bucket vectors stay in the context for wh_hh_aggregate* / wh_hh_buckets. */
 int32_t wh_hh_eval_and_check_batch(wh_ctx *ctx, const uint8_t verify_key[16], const uint8_t *keys, uint64_t stride, uint64_t n,
                                    uint32_t depth, uint8_t *tags, uint8_t *testing_ids, int32_t *status);

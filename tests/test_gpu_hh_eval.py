@@ -234,3 +234,62 @@ def test_mutated_key_chains_differential_fuzz(depth):
             assert (status == 0).any()
     finally:
         h.close()
+
+
+@pytest.mark.parametrize("depth,clients,reps,subbatch", [(5, 23, 3, None), (9, 12, 2, "7"), (9, 12, 2, "1"), (11, 3, 2, None), (1, 5, 1, None)])
+def test_sketch_sum_and_subtract_match_materialised_sum(monkeypatch, depth, clients, reps, subbatch):
+    """wh_hh_eval_and_sketch_batch_dev (the caller holds no bucket vectors: sub-batches are summed into the sketches on a side
+    stream) + wh_hh_sketch_subtract_dev ("sum all, subtract the rejected": re-expansion with atomic subtraction) against the
+    materialised path: same tags / ids / status, and per repetition the same sketch as aggregate_hhs over the kept key chains --
+    with malformed key chains, sub-batches that straddle repetitions, and accumulation into a running sketch."""
+    import torch
+    from whisper_amd import hh
+    if subbatch:
+        monkeypatch.setenv("WH_HH_SUBBATCH", subbatch)
+    vk = bytes(range(40, 56))
+    n = clients * reps
+    A, _, _, _ = _make(depth, n, 500 + depth)
+    A = A.copy()
+    A[1, 17 + 16] ^= 0xff            # key chain 1: broken bincode length -> WH_ERR_KEY_FORMAT, contributes nothing
+    A[n - 1, 16] = 9                 # the last one: bad key id
+    N, words = 1 << depth, (1 << depth) * 258
+    dev = torch.device("cuda:0")
+    h = hh.HeavyHitters(N)
+    try:
+        tags0, ids0, status0 = h.eval_and_check(vk, A)
+        dat = h.buckets()
+        assert status0[1] != 0 and status0[n - 1] != 0 and int((status0 != 0).sum()) == 2
+        rejected = sorted({0, 1, clients // 2, n - 2, n - 1} & set(range(n)))        # the group test's verdict (by index)
+        keep = np.ones(n, np.uint8)
+        keep[rejected] = 0
+        want_all = np.stack([dat[r * clients:(r + 1) * clients].sum(axis=0, dtype=np.uint32) for r in range(reps)])
+        want_kept = np.stack([(dat[r * clients:(r + 1) * clients] * keep[r * clients:(r + 1) * clients, None, None]).sum(axis=0, dtype=np.uint32)
+                              for r in range(reps)])
+        d_keys = torch.from_numpy(A).to(dev)
+        d_sk = torch.full((reps, N, 258), 12345, dtype=torch.int32, device=dev)
+        d_tags = torch.zeros((n, 64), dtype=torch.uint8, device=dev)
+        d_ids = torch.zeros((n, 16), dtype=torch.uint8, device=dev)
+        d_status = torch.full((n,), 99, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        for rnd in range(2):                                   # twice: the second call overwrites, it does not accumulate
+            h.eval_and_sketch_dev(vk, d_keys.data_ptr(), A.shape[1], n, clients, d_sk.data_ptr(), d_tags.data_ptr(), d_ids.data_ptr(), d_status.data_ptr())
+            h.synchronize()
+            assert np.array_equal(d_sk.cpu().numpy().view(np.uint32), want_all), rnd
+        assert np.array_equal(d_status.cpu().numpy(), status0)
+        got_tags = d_tags.cpu().numpy()
+        for i in range(n):
+            assert bytes(got_tags[i]) == (tags0[i].encode() if status0[i] == 0 else bytes(64))
+        assert [int.from_bytes(bytes(r), "little") for r in d_ids.cpu().numpy()] == ids0
+        h.sketch_subtract_dev(vk, d_keys.data_ptr(), A.shape[1], rejected, clients, d_sk.data_ptr())
+        h.synchronize()
+        assert np.array_equal(d_sk.cpu().numpy().view(np.uint32), want_kept)
+        # streaming: a second slice accumulates into the running sketch (CountSketch::insert)
+        h.eval_and_sketch_dev(vk, d_keys.data_ptr(), A.shape[1], n, clients, d_sk.data_ptr(), d_tags.data_ptr(), d_ids.data_ptr(), d_status.data_ptr(),
+                              accumulate=True)
+        h.synchronize()
+        assert np.array_equal(d_sk.cpu().numpy().view(np.uint32), want_kept + want_all)
+        # nothing was materialised by the fused call
+        with pytest.raises(Exception):
+            h.aggregate_hhs(None)
+    finally:
+        h.close()

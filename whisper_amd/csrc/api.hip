@@ -85,6 +85,7 @@ struct wh_ctx {
     int32_t *d_hh_status = nullptr; uint64_t hh_status_cap = 0;
     uint8_t *d_hh_keep = nullptr; uint64_t hh_keep_cap = 0;
     uint32_t *d_hh_acc = nullptr; uint64_t hh_acc_cap = 0;
+    uint32_t *d_hh_part = nullptr; uint64_t hh_part_cap = 0;   // one sub-batch of bucket vectors on their way into sketches (wh_hh_eval_and_sketch_batch_dev)
     // testing-id sort (sort.hip)
     uint32_t *d_sort_tmp = nullptr; uint64_t sort_tmp_cap = 0;
     uint32_t *d_sort_hist = nullptr; uint64_t sort_hist_cap = 0;
@@ -352,7 +353,7 @@ void wh_ctx_destroy(wh_ctx *c) {
                     c->d_blob, c->d_offsets, c->d_tags, c->d_ids, c->d_prep, c->W.desc, c->W.scal, c->W.weights, c->W.wlimbs, c->W.pows, c->W.rlc,
                     c->W.hrows, c->W.hlist, c->W.llist, c->W.dirty, c->W.counters,
                     c->d_omega2m, c->d_twist, c->d_hh_tab, c->hh_w.tpc, c->hh_w.proofblk, c->hh_w.supd, c->hh_w.buckg, c->d_hh_dat, c->d_hh_keys, c->d_hh_tags,
-                    c->d_hh_ids, c->d_hh_status, c->d_hh_keep, c->d_hh_acc, c->d_sort_tmp, c->d_sort_hist, c->d_bad_ids};
+                    c->d_hh_ids, c->d_hh_status, c->d_hh_keep, c->d_hh_acc, c->d_hh_part, c->d_sort_tmp, c->d_sort_hist, c->d_bad_ids};
     for (void *p : ptrs) if (p) hipFree(p);
     if (c->h_bad) hipHostFree(c->h_bad);
     if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
@@ -1058,22 +1059,26 @@ int32_t wh_f128_sum_rows_dev(wh_ctx *c, const uint8_t *d_rows, uint64_t n_rows, 
     return sum_rows(c, reinterpret_cast<const F128 *>(d_rows), d_keep, n_rows, len, reinterpret_cast<F128 *>(d_out));
 }
 
-static int32_t hh_sum(wh_ctx *c, const uint32_t *d_buckets, const uint8_t *d_keep, uint64_t n, uint64_t words,
-                      uint32_t *d_acc, bool zero_first) {
-    if (!c || !d_acc || !words || (n && !d_buckets)) return WH_ERR_PARAM;
-    WH_LOCK(c);
-    HIPCHK(c, hipSetDevice(c->device));
-    if (zero_first) HIPCHK(c, hipMemsetAsync(d_acc, 0, words * 4, c->stream));
+// acc[words] += sum of the kept rows of buckets[n][words] (no zeroing), on stream st
+static int32_t hh_sum_on(wh_ctx *c, hipStream_t st, const uint32_t *d_buckets, const uint8_t *d_keep, uint64_t n, uint64_t words, uint32_t *d_acc) {
     if (!n) return WH_OK;
     const uint32_t gx = (uint32_t)((words + 4 * 256 - 1) / (4 * 256));
     // enough (x, y) blocks to fill the chip: target ~4096 blocks
     uint32_t gy = 4096 / gx; if (gy < 1) gy = 1; if (gy > n) gy = (uint32_t)n; if (gy > 65535) gy = 65535;
     const uint32_t cpb = (uint32_t)((n + gy - 1) / gy);
     gy = (uint32_t)((n + cpb - 1) / cpb);
-    { KTimer t_(c, WH_K_HH);
-    hipLaunchKernelGGL(k_hh_sum_u32, dim3(gx, gy), dim3(256), 0, c->stream, d_buckets, d_keep, n, words, cpb, d_acc); }
+    hipLaunchKernelGGL(k_hh_sum_u32, dim3(gx, gy), dim3(256), 0, st, d_buckets, d_keep, n, words, cpb, d_acc);
     HIPCHK(c, hipGetLastError());
     return WH_OK;
+}
+static int32_t hh_sum(wh_ctx *c, const uint32_t *d_buckets, const uint8_t *d_keep, uint64_t n, uint64_t words,
+                      uint32_t *d_acc, bool zero_first) {
+    if (!c || !d_acc || !words || (n && !d_buckets)) return WH_ERR_PARAM;
+    WH_LOCK(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (zero_first) HIPCHK(c, hipMemsetAsync(d_acc, 0, words * 4, c->stream));
+    KTimer t_(c, WH_K_HH);
+    return hh_sum_on(c, c->stream, d_buckets, d_keep, n, words, d_acc);
 }
 int32_t wh_hh_bucket_sum_u32_dev(wh_ctx *c, const uint32_t *d_buckets, const uint8_t *d_keep, uint64_t n, uint64_t words,
                                  uint32_t *d_acc) {
@@ -1131,19 +1136,17 @@ static int32_t hh_workspace(wh_ctx *c, uint64_t cap, uint32_t depth) {
     return WH_OK;
 }
 
-int32_t wh_hh_eval_and_check_batch_dev(wh_ctx *c, const uint8_t verify_key[16], const uint8_t *d_keys, uint64_t stride, uint64_t n,
-                                       uint32_t depth, uint32_t *d_dat, uint8_t *d_tags, uint8_t *d_ids, int32_t *d_status) {
-    if (!c || !verify_key || depth < 1 || depth > HH_MAX_DEPTH || (n && (!d_keys || !d_tags || !d_ids || !d_status))) return WH_ERR_PARAM;
-    WH_LOCK(c);
-    if (stride < HhLayout(depth).total || n > 0x7fffffffull) return WH_ERR_PARAM;
+// eval_and_check of n key chains, sub-batch by sub-batch.  d_dat != NULL: the bucket vectors are materialised there.
+// d_sketch != NULL: they are summed into sketch (index / group_size) -- from a sub-batch of materialised vectors in context
+// scratch, by k_hh_sum_u32 on the side stream UNDER the latency-bound support / chain / final kernels of the same sub-batch
+// (summing inside the expansion with atomics is three times slower: vdpf.hip, HhSketchOut).
+static int32_t hh_eval(wh_ctx *c, const uint8_t verify_key[16], const uint8_t *d_keys, uint64_t stride, uint64_t n, uint32_t depth,
+                       uint32_t *d_dat, uint32_t *d_sketch, uint64_t group_size, int32_t accumulate, uint8_t *d_tags, uint8_t *d_ids,
+                       int32_t *d_status) {
     HIPCHK(c, hipSetDevice(c->device));
     int32_t rc;
     if ((rc = hh_tables(c, verify_key))) return rc;
     const uint64_t words = (uint64_t)HH_BKT << depth;
-    if (!d_dat) {
-        if ((rc = ensure(c, c->d_hh_dat, c->hh_dat_cap, (n ? n : 1) * words))) return rc;
-        d_dat = c->d_hh_dat;
-    }
     // sub-batches bound the scratch (64 B per leaf for the proof chain): at most 16384 key chains or 2 GiB at a time
     uint64_t cap = (2ull << 30) / (64ull << depth);
     if (cap > 16384) cap = 16384;
@@ -1153,18 +1156,91 @@ int32_t wh_hh_eval_and_check_batch_dev(wh_ctx *c, const uint8_t verify_key[16], 
     }
     if (cap > n) cap = n ? n : 1;
     if ((rc = hh_workspace(c, cap, depth))) return rc;
-    c->d_hh_dat_last = d_dat; c->hh_n_last = n; c->hh_depth_last = depth;
+    const bool sketch = d_sketch && n;
+    if (sketch) {
+        if ((rc = ensure(c, c->d_hh_part, c->hh_part_cap, cap * words))) return rc;       // one sub-batch of bucket vectors
+        const uint64_t n_sk = (n + group_size - 1) / group_size;
+        if (!accumulate) HIPCHK(c, hipMemsetAsync(d_sketch, 0, n_sk * words * 4, c->stream));
+    }
     for (uint64_t base = 0; base < n; base += cap) {
         const uint32_t m = (uint32_t)(n - base < cap ? n - base : cap);
         const uint8_t *kp = d_keys + base * stride;
+        uint32_t *dat_b = sketch ? c->d_hh_part : (d_dat ? d_dat + base * words : nullptr);
+        // the scratch vectors of the sub-batch before are still being summed on the side stream
+        if (sketch && base) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         int e;
         { KTimer t_(c, WH_K_HH_MAIN);
-          e = launch_hh_main(kp, stride, m, depth, c->d_hh_tab, c->hh_w, d_dat + base * words, d_ids + 16 * base, d_status + base, c->stream); }
-        if (!e) { KTimer t_(c, WH_K_HH_SUPPORT); e = launch_hh_support(kp, stride, m, depth, c->d_hh_tab, c->hh_w, d_status + base, c->stream); }
+          e = launch_hh_main(kp, stride, m, depth, c->d_hh_tab, c->hh_w, dat_b, d_ids + 16 * base, d_status + base, HhSketch{}, c->stream); }
+        if (e) { c->err = std::string("heavy-hitter eval launch: ") + hipGetErrorString((hipError_t)e); return WH_ERR_HIP; }
+        if (sketch) {
+            HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+            KTimer t_(c, WH_K_HH, c->stream2);
+            for (uint64_t lo = base; lo < base + m;) {           // the stretch of each sketch inside this sub-batch
+                const uint64_t g = lo / group_size, hi = std::min<uint64_t>(base + m, (g + 1) * group_size);
+                if ((rc = hh_sum_on(c, c->stream2, c->d_hh_part + (lo - base) * words, nullptr, hi - lo, words, d_sketch + g * words))) return rc;
+                lo = hi;
+            }
+            HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
+        }
+        { KTimer t_(c, WH_K_HH_SUPPORT); e = launch_hh_support(kp, stride, m, depth, c->d_hh_tab, c->hh_w, d_status + base, c->stream); }
         if (!e) { KTimer t_(c, WH_K_HH_CHAIN); e = launch_hh_chain(kp, stride, m, depth, c->d_hh_tab, c->hh_w, d_status + base, c->stream); }
         if (!e) { KTimer t_(c, WH_K_HH_FINAL); e = launch_hh_final(kp, stride, m, depth, c->hh_w, d_tags + 64 * base, d_status + base, c->stream); }
         if (e) { c->err = std::string("heavy-hitter eval launch: ") + hipGetErrorString((hipError_t)e); return WH_ERR_HIP; }
     }
+    if (sketch) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    return WH_OK;
+}
+
+int32_t wh_hh_eval_and_check_batch_dev(wh_ctx *c, const uint8_t verify_key[16], const uint8_t *d_keys, uint64_t stride, uint64_t n,
+                                       uint32_t depth, uint32_t *d_dat, uint8_t *d_tags, uint8_t *d_ids, int32_t *d_status) {
+    if (!c || !verify_key || depth < 1 || depth > HH_MAX_DEPTH || (n && (!d_keys || !d_tags || !d_ids || !d_status))) return WH_ERR_PARAM;
+    WH_LOCK(c);
+    if (stride < HhLayout(depth).total || n > 0x7fffffffull) return WH_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    int32_t rc;
+    const uint64_t words = (uint64_t)HH_BKT << depth;
+    if (!d_dat) {
+        if ((rc = ensure(c, c->d_hh_dat, c->hh_dat_cap, (n ? n : 1) * words))) return rc;
+        d_dat = c->d_hh_dat;
+    }
+    c->d_hh_dat_last = d_dat; c->hh_n_last = n; c->hh_depth_last = depth;
+    return hh_eval(c, verify_key, d_keys, stride, n, depth, d_dat, nullptr, 0, 0, d_tags, d_ids, d_status);
+}
+
+int32_t wh_hh_eval_and_sketch_batch_dev(wh_ctx *c, const uint8_t verify_key[16], const uint8_t *d_keys, uint64_t stride, uint64_t n,
+                                        uint32_t depth, uint64_t group_size, uint32_t *d_sketch, int32_t accumulate, uint8_t *d_tags,
+                                        uint8_t *d_ids, int32_t *d_status) {
+    if (!c || !verify_key || depth < 1 || depth > HH_MAX_DEPTH || !group_size || (n && (!d_keys || !d_sketch || !d_tags || !d_ids || !d_status)))
+        return WH_ERR_PARAM;
+    WH_LOCK(c);
+    if (stride < HhLayout(depth).total || n > 0x7fffffffull) return WH_ERR_PARAM;
+    c->d_hh_dat_last = nullptr; c->hh_n_last = 0;          // nothing materialised: wh_hh_buckets / wh_hh_aggregate have no batch
+    return hh_eval(c, verify_key, d_keys, stride, n, depth, nullptr, d_sketch, group_size, accumulate, d_tags, d_ids, d_status);
+}
+
+// "sum all, then subtract the bad ones": re-expand the key chains the group test rejected and take their bucket vectors out
+// of the sketches they went into (exact in Z/2^32).  Only the buckets are recomputed (no proof chain, no tags).
+int32_t wh_hh_sketch_subtract_dev(wh_ctx *c, const uint8_t verify_key[16], const uint8_t *d_keys, uint64_t stride, uint32_t depth,
+                                  const uint64_t *bad_index, uint64_t n_bad, uint64_t group_size, uint32_t *d_sketch) {
+    if (!c || !verify_key || depth < 1 || depth > HH_MAX_DEPTH || !group_size || (n_bad && (!d_keys || !bad_index || !d_sketch))) return WH_ERR_PARAM;
+    WH_LOCK(c);
+    if (stride < HhLayout(depth).total || n_bad > 0x7fffffffull) return WH_ERR_PARAM;
+    if (!n_bad) return WH_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int32_t rc;
+    if ((rc = hh_tables(c, verify_key))) return rc;
+    if ((rc = ensure(c, c->d_tmp_a, c->tmp_a_cap, 4 * n_bad))) return rc;
+    std::vector<uint32_t> idx(n_bad);
+    for (uint64_t i = 0; i < n_bad; i++) { if (bad_index[i] > 0x7fffffffull) return WH_ERR_PARAM; idx[i] = (uint32_t)bad_index[i]; }
+    HIPCHK(c, hipMemcpyAsync(c->d_tmp_a, idx.data(), 4 * n_bad, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));            // `idx` is a local
+    HhSketch sk;
+    sk.sketch = d_sketch; sk.group_size = group_size; sk.kidx = reinterpret_cast<const uint32_t *>(c->d_tmp_a); sk.flip = 1; sk.buckets_only = true;
+    int e;
+    { KTimer t_(c, WH_K_HH_MAIN);
+      e = launch_hh_main(d_keys, stride, (uint32_t)n_bad, depth, c->d_hh_tab, c->hh_w, nullptr, nullptr, nullptr, sk, c->stream); }
+    if (e) { c->err = std::string("sketch subtract launch: ") + hipGetErrorString((hipError_t)e); return WH_ERR_HIP; }
     return WH_OK;
 }
 

@@ -36,9 +36,20 @@ struct HhWork {
     uint32_t *buckg;     // [cap][258]     sum of the main key's outputs over all leaves
 };
 
-// the four launches of one sub-batch, in this order on one stream; each returns a hipError_t as int
+// atomic sketch accumulation of k_hh_main (vdpf.hip: HhSketchOut); sketch == NULL: none
+struct HhSketch {
+    uint32_t *sketch = nullptr;     // [sketches][2^depth * 258]
+    uint64_t group_size = 1;        // key chain g adds into sketch g / group_size
+    uint64_t first = 0;             // index of the launch's first key chain in the caller's array (kidx == NULL)
+    const uint32_t *kidx = nullptr; // launch slot -> key chain index (d_keys then is the whole array)
+    uint32_t flip = 0;              // 1: subtract
+    bool buckets_only = false;      // a subtract launch: no leaf hashes, no per-key sums
+};
+// the four launches of one sub-batch, in this order on one stream; each returns a hipError_t as int.  d_keys is the
+// launch's first key chain (kidx == NULL) or the whole array (kidx != NULL); d_dat, d_ids, d_status may be NULL.
 int launch_hh_main(const uint8_t *d_keys, uint64_t stride, uint32_t n, uint32_t depth, const HhTables *d_tab, const HhWork &w,
-                   uint32_t *d_dat, uint8_t *d_ids, int32_t *d_status, hipStream_t stream);
+                   uint32_t *d_dat, uint8_t *d_ids, int32_t *d_status, const HhSketch &sk, hipStream_t stream);
+
 int launch_hh_support(const uint8_t *d_keys, uint64_t stride, uint32_t n, uint32_t depth, const HhTables *d_tab, const HhWork &w,
                       const int32_t *d_status, hipStream_t stream);
 int launch_hh_chain(const uint8_t *d_keys, uint64_t stride, uint32_t n, uint32_t depth, const HhTables *d_tab, const HhWork &w,

@@ -266,11 +266,26 @@ __device__ __forceinline__ bool hh_prepare(const TabRef &T, const HhTables *__re
     return true;
 }
 
+// Where the bucket vectors go.  dat: every key chain's Vec<Bucket<u32>> (NULL: not materialised).  sketch: atomic adds
+// straight into a sketch, key chain g (its index in the caller's array) into sketch number g / group_size, flip = 1
+// subtracting -- the way the few key chains the group test rejected are taken out of a sum again.  Measured on MI355X
+// (profiles/r2_hh_fused_atomics.txt): one atomic per counter sustains 0.34 TB/s of added bytes, three times slower than
+// writing the vectors and summing them (k_hh_sum_u32), with device-scope atomics and with per-XCD partial sketches
+// alike; so whole batches are summed from materialised vectors (api.hip: hh_eval) and this path serves the subtraction.
+// In such a launch (tpc == NULL) only the buckets are computed.
+struct HhSketchOut {
+    uint32_t *sketch;          // NULL: no accumulation
+    uint64_t group_size, first;
+    const uint32_t *kidx;      // launch slot -> key chain index (NULL: first + slot)
+    uint32_t flip;
+};
+__device__ __forceinline__ void sk_add(uint32_t *p, uint32_t v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 template <int NT>
 __global__ __launch_bounds__(1024) void k_hh_main(const uint8_t *__restrict__ keys, uint64_t stride, uint32_t n, uint32_t depth,
                                                   const HhTables *__restrict__ tab, uint32_t *__restrict__ dat,
                                                   uint4 *__restrict__ tpc, uint32_t *__restrict__ buckg,
-                                                  uint8_t *__restrict__ ids, int32_t *__restrict__ status) {
+                                                  uint8_t *__restrict__ ids, int32_t *__restrict__ status, HhSketchOut so) {
     extern __shared__ uint32_t lds[];
     const uint32_t N = 1u << depth, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint32_t *Tall = lds;
@@ -288,11 +303,18 @@ __global__ __launch_bounds__(1024) void k_hh_main(const uint8_t *__restrict__ ke
     const TabRef T = tab_ref(Tall, tid);
     const uint32_t *rk0 = tab->rk[0];
     const uint32_t G = gridDim.x;
+    const uint64_t words = (uint64_t)N * HH_BKT;
+    // a subtract launch has nowhere to put testing ids (the caller has them): the producer writes them into LDS instead
+    __shared__ uint8_t id_lds[16];
+    // `keys` starts at the launch's first key chain (kidx == NULL) or is the caller's whole array (kidx != NULL)
+    auto key_slot = [&](uint32_t k) -> uint64_t { return so.kidx ? so.kidx[k] : k; };
+    auto key_index = [&](uint32_t k) -> uint64_t { return so.kidx ? so.kidx[k] : so.first + k; };
+    uint32_t *sk_base = so.sketch;
 
     if (producer) {
         const uint32_t k = blockIdx.x;
-        const bool ok = hh_prepare<NT>(T, tab, keys + (uint64_t)k * stride, depth, lane, hdr_b, seeds_b, cbits, ids + 16ull * k);
-        if (lane == 0) { okf[0] = ok; status[k] = ok ? 0 : HH_ERR_KEY_FORMAT; }
+        const bool ok = hh_prepare<NT>(T, tab, keys + key_slot(k) * stride, depth, lane, hdr_b, seeds_b, cbits, ids ? ids + 16ull * k : id_lds);
+        if (lane == 0) { okf[0] = ok; if (status) status[k] = ok ? 0 : HH_ERR_KEY_FORMAT; }
     }
     __syncthreads();
 
@@ -306,15 +328,18 @@ __global__ __launch_bounds__(1024) void k_hh_main(const uint8_t *__restrict__ ke
         if (producer) {
             const uint32_t kn = k + G;
             if (kn < n) {
-                const bool ok = hh_prepare<NT>(T, tab, keys + (uint64_t)kn * stride, depth, lane, hdr_b + (cur ^ 1) * HDR_BYTES,
-                                               seeds_b + (cur ^ 1) * N, cbits, ids + 16ull * kn);
-                if (lane == 0) { okf[cur ^ 1] = ok; status[kn] = ok ? 0 : HH_ERR_KEY_FORMAT; }
+                const bool ok = hh_prepare<NT>(T, tab, keys + key_slot(kn) * stride, depth, lane, hdr_b + (cur ^ 1) * HDR_BYTES,
+                                               seeds_b + (cur ^ 1) * N, cbits, ids ? ids + 16ull * kn : id_lds);
+                if (lane == 0) { okf[cur ^ 1] = ok; if (status) status[kn] = ok ? 0 : HH_ERR_KEY_FORMAT; }
             }
         } else if (!okf[cur]) {
-            uint32_t *d = dat + leaf0 * HH_BKT;
-            for (uint64_t q = tid; q < (uint64_t)N * HH_BKT; q += CONSUMERS) d[q] = 0;
+            if (dat) {
+                uint32_t *d = dat + leaf0 * HH_BKT;
+                for (uint64_t q = tid; q < words; q += CONSUMERS) d[q] = 0;
+            }
         } else {
-            const bool negate = hdr[L.key_id] != 0;
+            const bool negate = (hdr[L.key_id] != 0) != (so.flip != 0);
+            uint32_t *sk = sk_base ? sk_base + (key_index(k) / so.group_size) * words : nullptr;
             // ---- per-leaf pieces that occupy one lane each, as one work list of 2N items:
             //  items [0, N): tilde_pi = mmo_hash2to4(seed, x) with x = IntModN::zero() at EVERY leaf (IntModN::one() has
             //    val 0, common/src/group.rs:448-453, so `x.add(&GIn::one())` never moves), corrected by cs when lsb(seed) = 1;
@@ -323,7 +348,7 @@ __global__ __launch_bounds__(1024) void k_hh_main(const uint8_t *__restrict__ ke
                 const uint32_t oc0 = ldb32(hdr + L.oc + 1024), oc1 = ldb32(hdr + L.oc + 1028);
                 uint32_t t0 = 0, t1 = 0;
 #pragma unroll 1
-                for (uint32_t it = tid; it < 2 * N; it += CONSUMERS) {
+                for (uint32_t it = tpc ? tid : N + tid; it < 2 * N; it += CONSUMERS) {
                     const uint32_t x = it & (N - 1);
                     const uint4 s = seeds[x];
                     const uint32_t m = 0u - (s.x & 1);
@@ -346,7 +371,8 @@ __global__ __launch_bounds__(1024) void k_hh_main(const uint8_t *__restrict__ ke
                         const B128 o = mmo<NT>(T, rk0, c);
                         uint32_t a = o.w[0] + (oc0 & m), b = o.w[1] + (oc1 & m);
                         if (negate) { a = 0u - a; b = 0u - b; }
-                        *reinterpret_cast<uint2 *>(dat + (leaf0 + x) * HH_BKT + 256) = make_uint2(a, b);
+                        if (dat) *reinterpret_cast<uint2 *>(dat + (leaf0 + x) * HH_BKT + 256) = make_uint2(a, b);
+                        if (sk) { sk_add(sk + (uint64_t)x * HH_BKT + 256, a); sk_add(sk + (uint64_t)x * HH_BKT + 257, b); }
                         t0 += a; t1 += b;
                     }
                 }
@@ -376,13 +402,24 @@ __global__ __launch_bounds__(1024) void k_hh_main(const uint8_t *__restrict__ ke
                         acc[q] += oa.w[q];
                         if (x1 != x) acc[q] += ob.w[q];
                     }
-                    uint2 *d = reinterpret_cast<uint2 *>(dat + (leaf0 + x) * HH_BKT + 4 * lane);  // 8-byte aligned only
-                    d[0] = make_uint2(oa.w[0], oa.w[1]);
-                    d[1] = make_uint2(oa.w[2], oa.w[3]);
-                    if (x1 != x) {
-                        d = reinterpret_cast<uint2 *>(dat + (leaf0 + x1) * HH_BKT + 4 * lane);
-                        d[0] = make_uint2(ob.w[0], ob.w[1]);
-                        d[1] = make_uint2(ob.w[2], ob.w[3]);
+                    if (dat) {
+                        uint2 *d = reinterpret_cast<uint2 *>(dat + (leaf0 + x) * HH_BKT + 4 * lane);  // 8-byte aligned only
+                        d[0] = make_uint2(oa.w[0], oa.w[1]);
+                        d[1] = make_uint2(oa.w[2], oa.w[3]);
+                        if (x1 != x) {
+                            d = reinterpret_cast<uint2 *>(dat + (leaf0 + x1) * HH_BKT + 4 * lane);
+                            d[0] = make_uint2(ob.w[0], ob.w[1]);
+                            d[1] = make_uint2(ob.w[2], ob.w[3]);
+                        }
+                    }
+                    if (sk) {
+                        uint32_t *pa = sk + (uint64_t)x * HH_BKT + 4 * lane, *pb = sk + (uint64_t)x1 * HH_BKT + 4 * lane;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) sk_add(pa + q, oa.w[q]);
+                        if (x1 != x) {
+#pragma unroll
+                            for (int q = 0; q < 4; q++) sk_add(pb + q, ob.w[q]);
+                        }
                     }
                 }
 #pragma unroll
@@ -391,7 +428,7 @@ __global__ __launch_bounds__(1024) void k_hh_main(const uint8_t *__restrict__ ke
         }
         __syncthreads();
         // this buffer's sums are complete; it is used again two key chains on, a barrier away
-        if (tid < HH_BKT) { buckg[(uint64_t)k * HH_BKT + tid] = red[tid]; red[tid] = 0; }
+        if (tid < HH_BKT) { if (buckg) buckg[(uint64_t)k * HH_BKT + tid] = red[tid]; red[tid] = 0; }
     }
 }
 
@@ -598,15 +635,17 @@ size_t hh_main_lds_bytes(uint32_t depth) {
 }
 
 int launch_hh_main(const uint8_t *d_keys, uint64_t stride, uint32_t n, uint32_t depth, const HhTables *d_tab, const HhWork &w,
-                   uint32_t *d_dat, uint8_t *d_ids, int32_t *d_status, hipStream_t stream) {
+                   uint32_t *d_dat, uint8_t *d_ids, int32_t *d_status, const HhSketch &sk, hipStream_t stream) {
     const size_t lds = hh_main_lds_bytes(depth);
     auto kmain = hh_main_tables(depth) == 4 ? k_hh_main<4> : k_hh_main<2>;
+    const HhSketchOut so{sk.sketch, sk.group_size ? sk.group_size : 1, sk.first, sk.kidx, sk.flip};
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kmain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const uint32_t grid = n < (uint32_t)cus ? n : (uint32_t)cus;   // one persistent workgroup per CU
-    hipLaunchKernelGGL(kmain, dim3(grid), dim3(MAIN_THREADS), lds, stream, d_keys, stride, n, depth, d_tab, d_dat, w.tpc, w.buckg, d_ids, d_status);
+    hipLaunchKernelGGL(kmain, dim3(grid), dim3(MAIN_THREADS), lds, stream, d_keys, stride, n, depth, d_tab, d_dat, sk.buckets_only ? nullptr : w.tpc,
+                       sk.buckets_only ? nullptr : w.buckg, d_ids, d_status, so);
     return (int)hipGetLastError();
 }
 static const size_t TAIL_LDS = 4 * (size_t)T_WORDS * TAIL_NT;

@@ -142,6 +142,21 @@ class HeavyHitters:
                                                      d_ids, d_status), "hh_eval_and_check_dev")
         self.n_last = n
 
+    def eval_and_sketch_dev(self, verify_key, d_keys, stride, n, group_size, d_sketch, d_tags, d_ids, d_status, accumulate=False):
+        """eval_and_check fused with aggregate_hhs' sum: key chain i is added into sketch i // group_size (device pointers, ints);
+        no bucket vectors are materialised.  Asynchronous."""
+        vk = np.frombuffer(bytes(verify_key), np.uint8).copy()
+        self._chk(lib.wh_hh_eval_and_sketch_batch_dev(self._ctx, vk.ctypes.data, d_keys, stride, n, self.depth, group_size, d_sketch,
+                                                      1 if accumulate else 0, d_tags, d_ids, d_status), "hh_eval_and_sketch_dev")
+        self.n_last = 0
+
+    def sketch_subtract_dev(self, verify_key, d_keys, stride, bad_index, group_size, d_sketch):
+        """Take the key chains d_keys[bad_index] (rejected by the group test) out of the sketches they were summed into."""
+        vk = np.frombuffer(bytes(verify_key), np.uint8).copy()
+        idx = np.ascontiguousarray(bad_index, dtype=np.uint64)
+        self._chk(lib.wh_hh_sketch_subtract_dev(self._ctx, vk.ctypes.data, d_keys, stride, self.depth, idx.ctypes.data if idx.size else None,
+                                                idx.size, group_size, d_sketch), "hh_sketch_subtract_dev")
+
     def buckets(self):
         """Vec<Bucket<u32>> of every key chain of the last batch: uint32 [n, num_buckets, 258]."""
         out = np.zeros((self.n_last, self.num_buckets, BUCKET_WORDS), np.uint32)
