@@ -220,6 +220,16 @@ int32_t wh_hh_bucket_sum_u32_dev(wh_ctx *ctx, const uint32_t *d_buckets, const u
 int32_t wh_hh_bucket_accumulate_u32_dev(wh_ctx *ctx, const uint32_t *d_buckets, const uint8_t *d_keep, uint64_t n,
                                         uint64_t words, uint32_t *d_acc);
 
+/* Extension with no counterpart in the reference: the same bucket sums over Field128 counters (16-byte little-endian
+ * residues; non-canonical inputs are reduced), for a deployment that swaps AggRing (hhcore/src/lib.rs:13 fixes it to u32;
+ * eval_and_check only converts to 16/32/64-bit rings, protocol.rs:157-173) for the Prio3 field -- BASELINE.json's streaming
+ * configuration names Field128.  buckets[n][words][16], keep[n] (NULL = all), acc[words][16]; _accumulate_ adds into acc
+ * (CountSketch::insert over batch_size slices).  Only the sum is built: no Field128 key-chain expansion exists. */
+int32_t wh_hh_bucket_sum_f128_dev(wh_ctx *ctx, const uint8_t *d_buckets, const uint8_t *d_keep, uint64_t n, uint64_t words,
+                                  uint8_t *d_acc);
+int32_t wh_hh_bucket_accumulate_f128_dev(wh_ctx *ctx, const uint8_t *d_buckets, const uint8_t *d_keep, uint64_t n, uint64_t words,
+                                         uint8_t *d_acc);
+
 /* replaces: the expansion loop of server-hh (server-hh/src/main.rs:163-174, 255-265) =
  *   Prf::compute_prf(key.id.to_le_bytes()) + BCSketch::eval_and_check::<IntModN<NumBuckets>> (hhcore/src/protocol.rs:78-176)
  *   = VDPFKey::eval_all of the main key and of the 257 support keys (hhcore/src/vdpf.rs:123-214; PRG and MMO hashes

@@ -43,7 +43,7 @@ EXPORTS = [
     "wh_test_f64_op", "wh_flp_query_batch", "wh_flp_decide_batch", "wh_flp_encode", "wh_flp_prove", "wh_hh_bucket_accumulate_u32_dev", "wh_prio3_prepare_init_batch_dev", "wh_prio3_prepare_init_batch", "wh_prio3_prepare_finish_batch",
     "wh_hh_key_chain_len", "wh_hh_ctx_create", "wh_hh_eval_and_check_batch_dev", "wh_hh_eval_and_check_batch", "wh_hh_buckets",
     "wh_hh_aggregate", "wh_hh_aggregate_dev", "wh_hh_gen_key_chain", "wh_flp_prove_batch", "wh_client_shard_many_gpu", "wh_sort_by_testing_id_dev", "wh_sort_by_testing_id", "wh_keep_mask_dev",
-    "wh_sort_by_testing_id_noalloc_dev", "wh_hh_eval_and_sketch_batch_dev", "wh_hh_sketch_subtract_dev", "wh_ctx_lock", "wh_ctx_unlock", "wh_host_alloc", "wh_host_free", "wh_comm_unique_id", "wh_comm_init", "wh_comm_destroy", "wh_comm_rank",
+    "wh_sort_by_testing_id_noalloc_dev", "wh_hh_bucket_sum_f128_dev", "wh_hh_bucket_accumulate_f128_dev", "wh_hh_eval_and_sketch_batch_dev", "wh_hh_sketch_subtract_dev", "wh_ctx_lock", "wh_ctx_unlock", "wh_host_alloc", "wh_host_free", "wh_comm_unique_id", "wh_comm_init", "wh_comm_destroy", "wh_comm_rank",
     "wh_prio3_allgather_reduce_dev", "wh_f128_allgather_reduce_dev", "wh_prio3_allgather_reduce", "wh_hh_allreduce_u32_dev",
 ]
 
@@ -106,6 +106,8 @@ lib.wh_hh_eval_and_check_batch_dev.argtypes = [vp, vp, vp, u64, u64, u32, vp, vp
 lib.wh_hh_eval_and_check_batch.argtypes = [vp, vp, vp, u64, u64, u32, vp, vp, vp]
 lib.wh_hh_eval_and_sketch_batch_dev.argtypes = [vp, vp, vp, u64, u64, u32, u64, vp, i32, vp, vp, vp]
 lib.wh_hh_sketch_subtract_dev.argtypes = [vp, vp, vp, u64, u32, vp, u64, u64, vp]
+lib.wh_hh_bucket_sum_f128_dev.argtypes = [vp, vp, vp, u64, u64, vp]
+lib.wh_hh_bucket_accumulate_f128_dev.argtypes = [vp, vp, vp, u64, u64, vp]
 lib.wh_hh_buckets.argtypes = [vp, vp]
 lib.wh_hh_aggregate.argtypes = [vp, vp, vp]
 lib.wh_hh_aggregate_dev.argtypes = [vp, vp, vp, i32]

@@ -999,18 +999,35 @@ __global__ void k_keep_eff(const uint8_t *keep, const int32_t *status, uint64_t 
     if (i < n) out[i] = (status[i] == 0) && (!keep || keep[i]);
 }
 
-static int32_t sum_rows(wh_ctx *c, const F128 *rows, const uint8_t *d_keep, uint64_t n, uint32_t len, F128 *d_out) {
+// d_out[len] = (extra ? extra : 0) + sum of the kept rows, mod p.  extra may be d_out itself (accumulate in place).
+static int32_t sum_rows(wh_ctx *c, const F128 *rows, const uint8_t *d_keep, uint64_t n, uint32_t len, F128 *d_out, const F128 *extra = nullptr) {
     int32_t rc;
+    if (n == 0) {
+        if (!extra) HIPCHK(c, hipMemsetAsync(d_out, 0, len * sizeof(F128), c->stream));
+        else if (extra != d_out) HIPCHK(c, hipMemcpyAsync(d_out, extra, len * sizeof(F128), hipMemcpyDeviceToDevice, c->stream));
+        return WH_OK;
+    }
+    KTimer t_(c, WH_K_AGG);
+    if (len >= 4096) {
+        // long rows (sketches): the columns alone fill the chip; a few slabs of rows on top
+        const uint32_t gx = (len + 255) / 256;
+        uint64_t gy = 4096 / gx; if (gy < 1) gy = 1; if (gy > n) gy = n; if (gy > 64) gy = 64;
+        const uint64_t rps = (n + gy - 1) / gy;
+        gy = (n + rps - 1) / rps;
+        if ((rc = ensure(c, c->d_partials, c->partials_cap, gy * len))) return rc;
+        hipLaunchKernelGGL(k_agg_partial_cols, dim3(gx, (uint32_t)gy), dim3(256), 0, c->stream, rows, d_keep, n, len, (uint32_t)rps, c->d_partials);
+        hipLaunchKernelGGL(k_agg_final, dim3((len + 15) / 16), dim3(256), 0, c->stream, c->d_partials, (uint32_t)gy, len, extra, d_out);
+        HIPCHK(c, hipGetLastError());
+        return WH_OK;
+    }
     const uint32_t tpr = len < 256 ? len : 256, rstep = 256 / tpr;
     // ~2048 blocks, each a slab of rows
     uint64_t rpb = (n + 2047) / 2048;
     if (rpb < rstep) rpb = rstep;
     const uint32_t nblocks = (uint32_t)((n + rpb - 1) / rpb);
-    if (n == 0) { HIPCHK(c, hipMemsetAsync(d_out, 0, len * sizeof(F128), c->stream)); return WH_OK; }
     if ((rc = ensure(c, c->d_partials, c->partials_cap, (uint64_t)nblocks * rstep * len))) return rc;
-    { KTimer t_(c, WH_K_AGG);
     hipLaunchKernelGGL(k_agg_partial, dim3(nblocks), dim3(256), 0, c->stream, rows, d_keep, n, len, (uint32_t)rpb, c->d_partials);
-    hipLaunchKernelGGL(k_agg_final, dim3((len + 15) / 16), dim3(256), 0, c->stream, c->d_partials, nblocks * rstep, len, d_out); }
+    hipLaunchKernelGGL(k_agg_final, dim3((len + 15) / 16), dim3(256), 0, c->stream, c->d_partials, nblocks * rstep, len, extra, d_out);
     HIPCHK(c, hipGetLastError());
     return WH_OK;
 }
@@ -1079,6 +1096,20 @@ static int32_t hh_sum(wh_ctx *c, const uint32_t *d_buckets, const uint8_t *d_kee
     if (zero_first) HIPCHK(c, hipMemsetAsync(d_acc, 0, words * 4, c->stream));
     KTimer t_(c, WH_K_HH);
     return hh_sum_on(c, c->stream, d_buckets, d_keep, n, words, d_acc);
+}
+// the same sums over a Field128 ring (BASELINE config 5 names it; the reference's AggRing is u32, hhcore/src/lib.rs:13)
+static int32_t hh_sum_f128(wh_ctx *c, const uint8_t *d_buckets, const uint8_t *d_keep, uint64_t n, uint64_t words, uint8_t *d_acc, bool accumulate) {
+    if (!c || !d_acc || !words || words > 0xffffffffull || (n && !d_buckets)) return WH_ERR_PARAM;
+    WH_LOCK(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    F128 *acc = reinterpret_cast<F128 *>(d_acc);
+    return sum_rows(c, reinterpret_cast<const F128 *>(d_buckets), d_keep, n, (uint32_t)words, acc, accumulate ? acc : nullptr);
+}
+int32_t wh_hh_bucket_sum_f128_dev(wh_ctx *c, const uint8_t *d_buckets, const uint8_t *d_keep, uint64_t n, uint64_t words, uint8_t *d_acc) {
+    return hh_sum_f128(c, d_buckets, d_keep, n, words, d_acc, false);
+}
+int32_t wh_hh_bucket_accumulate_f128_dev(wh_ctx *c, const uint8_t *d_buckets, const uint8_t *d_keep, uint64_t n, uint64_t words, uint8_t *d_acc) {
+    return hh_sum_f128(c, d_buckets, d_keep, n, words, d_acc, true);
 }
 int32_t wh_hh_bucket_sum_u32_dev(wh_ctx *c, const uint32_t *d_buckets, const uint8_t *d_keep, uint64_t n, uint64_t words,
                                  uint32_t *d_acc) {

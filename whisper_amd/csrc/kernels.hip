@@ -1041,8 +1041,25 @@ __global__ void __launch_bounds__(256) k_agg_partial(const F128 *rows, const uin
         partials[((uint64_t)blockIdx.x * rstep + sub) * len + e] = acc;
     }
 }
-// second pass over the partial sums: 16 columns per workgroup, 16 lanes down each column
-__global__ void __launch_bounds__(256) k_agg_final(const F128 *partials, uint32_t nparts, uint32_t len, F128 *out) {
+// Long rows (a Field128 sketch: 258 x 2^depth elements): thread per column, grid.y slabs of rows, one partial row per slab
+__global__ void __launch_bounds__(256) k_agg_partial_cols(const F128 *rows, const uint8_t *keep, uint64_t n, uint32_t len,
+                                                          uint32_t rows_per_slab, F128 *partials) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= len) return;
+    const uint64_t r0 = (uint64_t)blockIdx.y * rows_per_slab, r1 = r0 + rows_per_slab < n ? r0 + rows_per_slab : n;
+    uint64_t lo = 0, hi = 0, ov = 0;
+    for (uint64_t r = r0; r < r1; r++) {
+        if (keep && !keep[r]) continue;
+        const F128 v = rows[r * len + e];
+        u128 s = (((u128)hi << 64) | lo) + f_u(v);
+        ov += s < f_u(v);
+        lo = (uint64_t)s; hi = (uint64_t)(s >> 64);
+    }
+    partials[(uint64_t)blockIdx.y * len + e] = f_reduce256(lo, hi, ov, 0);
+}
+// second pass over the partial sums: 16 columns per workgroup, 16 lanes down each column; `extra` (may be NULL, may be
+// `out`) is one more row: the running sum of an accumulating caller
+__global__ void __launch_bounds__(256) k_agg_final(const F128 *partials, uint32_t nparts, uint32_t len, const F128 *extra, F128 *out) {
     __shared__ F128 red[256];
     const uint32_t col = blockIdx.x * 16 + (threadIdx.x & 15), grp = threadIdx.x >> 4;
     uint64_t lo = 0, hi = 0, ov = 0;
@@ -1059,7 +1076,11 @@ __global__ void __launch_bounds__(256) k_agg_final(const F128 *partials, uint32_
         if (grp < s) red[threadIdx.x] = f_add(red[threadIdx.x], red[threadIdx.x + 16 * s]);
         __syncthreads();
     }
-    if (grp == 0 && col < len) out[col] = red[threadIdx.x];
+    if (grp == 0 && col < len) {
+        F128 v = red[threadIdx.x];
+        if (extra) { const F128 x = extra[col]; v = f_add(v, f_reduce256(x.lo, x.hi, 0, 0)); }
+        out[col] = v;
+    }
 }
 
 // Heavy hitters (server-hh/src/main.rs:72-104, hhcore/src/bucket.rs:48-55): per-counter u32

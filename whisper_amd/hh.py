@@ -179,6 +179,11 @@ class HeavyHitters:
         fn = lib.wh_hh_bucket_accumulate_u32_dev if accumulate else lib.wh_hh_bucket_sum_u32_dev
         self._chk(fn(self._ctx, d_buckets, d_keep, n, words, d_acc), "hh_bucket_sum")
 
+    def bucket_sum_f128_dev(self, d_buckets, d_keep, n, words, d_acc, accumulate=False):
+        """The Field128 extension of aggregate_hhs: buckets[n][words] of 16-byte residues -> acc[words] (device pointers)."""
+        fn = lib.wh_hh_bucket_accumulate_f128_dev if accumulate else lib.wh_hh_bucket_sum_f128_dev
+        self._chk(fn(self._ctx, d_buckets, d_keep, n, words, d_acc), "hh_bucket_sum_f128")
+
     def sort_by_testing_id_dev(self, d_ids, n, d_order, d_tags=None, tag_bytes=64, d_sorted_ids=None, d_sorted_tags=None):
         """The server's stable sort by testing id (server-hh/src/main.rs:175, 266) on device buffers (raw pointers)."""
         self._chk(lib.wh_sort_by_testing_id_dev(self._ctx, d_ids, n, d_order, d_tags, tag_bytes, d_sorted_ids, d_sorted_tags),
