@@ -41,20 +41,20 @@ enum : uint32_t { LANE_FULL = 0, LANE_SQUEEZE = 1, LANE_ABSORB = 2 };
 // Equal shares of a SIMD's issue slots.  A SIMD picks the oldest ready wavefront first: of the three sponge wavefronts it
 // holds, two run at nearly full speed and the third gets what is left, so the two finish early and the third then runs
 // its chain alone at the issue rate of a lone wavefront (measured with tools/meas_bench.hip: the three end after 17, 26
-// and 36 ms).  Each wavefront therefore sets its user priority from the shader clock, which the wavefronts of a SIMD
-// read alike: epochs of 2^WH_PRIO_EPOCH_LOG2 cycles, rank = (wave slot + epoch) mod 3, so that at any time the three hold
-// the three ranks and over three epochs each has had every rank.
+// and 36 ms).  Each wavefront therefore takes its priority outside the rotation runs of the permutation (keccak.hpp:
+// keccak_f1600_ranked) from the shader clock, which the wavefronts of a SIMD read alike: epochs of 2^WH_PRIO_EPOCH_LOG2
+// cycles, rank = (wave slot + epoch) mod 3, so that at any time the three hold the three ranks and over three epochs each
+// has had every rank.
 #ifndef WH_PRIO_EPOCH_LOG2
 #define WH_PRIO_EPOCH_LOG2 21
 #endif
 __device__ __forceinline__ uint32_t wave_slot() { return __builtin_amdgcn_s_getreg((3 << 11) | 4); }   // HW_ID.wave_id
-__device__ __forceinline__ void rotate_prio(uint32_t slot) {
+__device__ __forceinline__ uint32_t rotate_prio(uint32_t slot) {
 #ifndef WH_MEAS_NO_ROTATE
     const uint32_t epoch = (uint32_t)(__builtin_amdgcn_s_memtime() >> WH_PRIO_EPOCH_LOG2);
-    const uint32_t r = __builtin_amdgcn_readfirstlane((slot + epoch) % 3);
-    if (r == 0) __builtin_amdgcn_s_setprio(0);
-    else if (r == 1) __builtin_amdgcn_s_setprio(1);
-    else __builtin_amdgcn_s_setprio(2);
+    return __builtin_amdgcn_readfirstlane((slot + epoch) % 3);
+#else
+    return 0;
 #endif
 }
 
@@ -79,8 +79,7 @@ __device__ __forceinline__ void absorb_whole_blocks(SpongeG &s, const uint8_t *p
         for (int i = 0; i < (int)RATE_WORDS; i++) s.st[i] ^= w[i];
         p += SHAKE128_RATE;
         if (b + 1 < nb) load_block(w, p);
-        rotate_prio(slot);
-        keccak_f1600(s.st);
+        keccak_f1600_ranked(s.st, rotate_prio(slot));
     }
 }
 
@@ -164,7 +163,7 @@ __device__ __forceinline__ void meas_body(const Prio3Dev &P, const Workspace &W,
 #pragma unroll 1
         for (uint32_t it = 0; it < iters; it++) {
             uint32_t prev_hi = 0, top = 0;
-            rotate_prio(slot);
+            const uint32_t rank = rotate_prio(slot);
             // even block e[0..20] is in the squeezer's state: absorber words 5..20 take e[0..15]
 #pragma unroll
             for (int w = 0; w < 16; w++) {
@@ -185,7 +184,7 @@ __device__ __forceinline__ void meas_body(const Prio3Dev &P, const Workspace &W,
                 for (int c = 0; c < 10; c++) st128g(out + 16 * c, F128{s.st[2 * c], s.st[2 * c + 1]});
             }
             const uint64_t carry = s.st[20];
-            keccak_f1600(s.st);
+            keccak_f1600_ranked(s.st, rank);
             // absorber: words 0..4 of its next block from e[15..20]; then o[0..15] into words 5..20
             {
                 uint64_t t[6];
@@ -217,7 +216,7 @@ __device__ __forceinline__ void meas_body(const Prio3Dev &P, const Workspace &W,
                 for (int c = 0; c < 10; c++) st128g(out + 176 + 16 * c, F128{s.st[2 * c + 1], s.st[2 * c + 2]});
             }
             out += 336;
-            keccak_f1600(s.st);
+            keccak_f1600_ranked(s.st, rank);
             {
                 uint64_t t[6];
 #pragma unroll
