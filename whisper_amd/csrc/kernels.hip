@@ -190,6 +190,14 @@ __device__ __forceinline__ void weights_and_tables(const Prio3Dev &P, const Work
 }
 
 // ---------------------------------------------------------------------------------- hash ----
+// Three wavefronts a SIMD (168 VGPRs) and no register prefetch of the next rate block: the absorbs here are short, and the
+// third wavefront is worth more than the loads in flight (4.45 -> 3.65 ms at 125 000 reports; four wavefronts spill 59).
+#ifndef WH_HASH_PREFETCH
+#define WH_HASH_PREFETCH false
+#endif
+#ifndef WH_HASH_ATTR
+#define WH_HASH_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
+#endif
 // Job A (lanes [0, npad)): five sponges (the own joint-rand part, prio3.rs:2543-2555, comes from
 //   k_meas) -- joint-rand
 //   seed (derive_joint_rand_seed :482-493 with the own part substituted, :2564-2578), joint
@@ -198,7 +206,7 @@ __device__ __forceinline__ void weights_and_tables(const Prio3Dev &P, const Work
 // Job B (lanes [npad, 2 npad)): hash of the public parts (:2808-2840), RLC coefficients
 //   (:2859-2862), testing id (main.rs:51).
 // All sponges of a lane go through one loop body; a wave-uniform switch picks the inputs.
-__global__ void __launch_bounds__(256) k_hash(Prio3Dev P, Workspace W, uint32_t npad, uint32_t jobs, uint64_t vk0,
+__global__ void __launch_bounds__(256) WH_HASH_ATTR k_hash(Prio3Dev P, Workspace W, uint32_t npad, uint32_t jobs, uint64_t vk0,
                                               uint64_t vk1, const uint8_t *aes_rk, uint8_t *testing_ids,
                                               int32_t *status) {
     uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
@@ -250,7 +258,7 @@ __global__ void __launch_bounds__(256) k_hash(Prio3Dev P, Workspace W, uint32_t 
             break;
         }
         s.init_xof(P.alg_id, usage, k0, k1);
-        s.absorb3(p1, l1, p2, l2, p3, l3);
+        s.absorb3<WH_HASH_PREFETCH>(p1, l1, p2, l2, p3, l3);
         s.finalize();
         if (emit_n) {
             xof_emit(s, emit_p, emit_n, P.sampler_bound);
