@@ -49,17 +49,21 @@ HH_WORKLOADS = {
                       desc="heavy hitters, recovery threshold 0.001: 17 repetitions x 2048 buckets, 250 clients/GPU"),
 }
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# Keccak-f[1600] on the vector ALUs.  A round is 122 full-rate instructions (v_bitop3_b32 / v_xor_b32: 2 cycles per wavefront
-# and SIMD, MI355X_MICROARCH.md "Per-instruction cycle constants") and 58 half-rate ones (v_alignbit_b32: 4 cycles), so a
-# wavefront-permutation costs 24 * (122 * 2 + 58 * 4) = 11 424 issue cycles and 1 024 SIMDs x 64 lanes at the 2.4 GHz maximum
-# clock give 13.8 G permutations/s: the issue-rate peak.  The measured ceiling of the same instruction stream with nothing else
-# in the kernel (tools/keccak_bench.hip, >= 4 wavefronts per SIMD, in-kernel clock 2.40 GHz, profiles/r2_keccak_bench.txt) is
-# 10.35 G/s = 15.2 k cycles per wavefront-permutation: the mix issues at 3.3 cycles per instruction, not 2.6.
-KECCAK_ISSUE_CYCLES = 24 * (122 * 2 + 58 * 4)
+# Keccak-f[1600] on the vector ALUs.  Measured issue model of a gfx950 SIMD (tools/inst_rate_gen.py, profiles/r2_inst_rate*.txt):
+# two VALU instructions start per four cycles, from two different wavefronts; the first slot takes anything, the second only
+# "full-rate" instructions (VOP1/VOP2 class, v_bitop3_b32), never v_alignbit_b32.  A round is 122 v_bitop3/v_xor and 58
+# v_alignbit: with the rotations in the first slot (keccak.hpp raises the wavefront's priority for them) the floor is
+# 180 instructions x 2 cycles = 360 cycles per wavefront-round, 8 640 per wavefront-permutation; 1 024 SIMDs x 64 lanes at the
+# 2.4 GHz maximum clock give 18.2 G permutations/s: the issue-rate peak.  The measured ceiling of the same round code with
+# nothing else in the kernel (tools/keccak_bench.hip after two seconds of load, profiles/r2b_keccak_bench.txt) is 13.69 G/s at
+# 6 wavefronts per SIMD and 12.96 G/s at 3, where the chip is power-limited (1.29 kW of its 1.4 kW cap, profiles/
+# r2_power_probe.txt) and holds 1.95-2.07 GHz, not 2.4.
+KECCAK_ISSUE_CYCLES = 24 * 180 * 2
 MAX_CLOCK_HZ = 2.4e9
 KECCAK_PEAK = 1024 * 64 * MAX_CLOCK_HZ / KECCAK_ISSUE_CYCLES
-KECCAK_PEAK_MEASURED = 10.35e9
-K_MEAS_CLOCK_GHZ = 2.23      # in-kernel clock of k_meas (s_memtime / s_memrealtime, tools/meas_bench.hip, profiles/r2_meas_bench_probe.txt)
+KECCAK_PEAK_MEASURED = 13.69e9
+KECCAK_PEAK_MEASURED_3_WAVES = 12.96e9
+K_MEAS_CLOCK_GHZ = 1.86      # in-kernel clock of k_meas (s_memtime / s_memrealtime, tools/meas_bench.hip, profiles/r2b_meas_bench.txt)
 
 
 def alg_bytes_per_report(s, role):
@@ -357,13 +361,16 @@ def roofline_obj(dom, kernels, meas_perms, meas_ms, hbm_achieved, traffic, traff
     ach = meas_perms / (meas_ms * 1e-3) / 1e9
     return {"bound": "valu", "kernel": "k_meas", "achieved": ach, "peak": KECCAK_PEAK / 1e9, "unit": "G Keccak-f[1600]/s",
             "frac": ach / (KECCAK_PEAK / 1e9), "traffic": traffic,
-            "peak_derivation": f"24 rounds x (122 full-rate x 2 + 58 half-rate x 4 cycles) = {KECCAK_ISSUE_CYCLES} issue cycles per wavefront-"
-                               f"permutation; 1024 SIMDs x 64 lanes x {MAX_CLOCK_HZ / 1e9} GHz",
+            "peak_derivation": f"24 rounds x 180 instructions x 2 cycles (two VALU issue slots per four cycles and SIMD, measured: "
+                               f"tools/inst_rate_gen.py) = {KECCAK_ISSUE_CYCLES} cycles per wavefront-permutation; 1024 SIMDs x 64 lanes x {MAX_CLOCK_HZ / 1e9} GHz",
             "peak_measured": KECCAK_PEAK_MEASURED / 1e9, "frac_of_measured": ach / (KECCAK_PEAK_MEASURED / 1e9),
-            "peak_measured_source": "tools/keccak_bench.hip, profiles/r2_keccak_bench.txt: same round code, nothing else, >= 4 waves/SIMD, in-kernel clock 2.40 GHz",
+            "peak_measured_source": "tools/keccak_bench.hip, profiles/r2b_keccak_bench.txt: same round code, nothing else, 6 waves/SIMD, power-limited at 1.95 GHz; "
+                                    f"{KECCAK_PEAK_MEASURED_3_WAVES / 1e9} at the 3 waves/SIMD k_meas has",
+            "frac_of_measured_3_waves": ach / (KECCAK_PEAK_MEASURED_3_WAVES / 1e9),
             "clock_ghz_in_kernel": K_MEAS_CLOCK_GHZ,
-            "frac_of_measured_at_kernel_clock": ach / (KECCAK_PEAK_MEASURED / 1e9 * K_MEAS_CLOCK_GHZ / 2.40),
-            "clock_source": "s_memtime / s_memrealtime stamps of a diagnostic build, tools/meas_bench.hip, profiles/r2_meas_bench_probe.txt",
+            "frac_of_peak_at_kernel_clock": ach / (KECCAK_PEAK / 1e9 * K_MEAS_CLOCK_GHZ * 1e9 / MAX_CLOCK_HZ),
+            "clock_source": "s_memtime / s_memrealtime stamps of a diagnostic build, tools/meas_bench.hip, profiles/r2b_meas_bench.txt; board power "
+                            "1.29 kW of 1.4 kW while the step runs (profiles/r2_power_probe.txt)",
             "keccak_f1600_per_launch": meas_perms, "avg_launch_ms": meas_ms, "hbm": hbm}
 
 
