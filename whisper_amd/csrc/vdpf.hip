@@ -6,7 +6,7 @@
 //                 leaf hashes (mmo_hash2to4, :202-241), leaf conversion into Bucket<u32> (convert -> refill8,
 //                 :180-198, 368-403) written to `dat`, the per-position sum over all leaves, the PRF testing id
 //   k_hh_support  one lane per support key
-//   k_hh_chain    one lane per key chain: pi <- pi ^ H'(pi ^ corrected leaf hash), leaf by leaf (vdpf.rs:197-200;
+//   k_hh_chain    sixteen lanes per key chain: pi <- pi ^ H'(pi ^ corrected leaf hash), leaf by leaf (vdpf.rs:197-200;
 //                 mmo_hash4to4, prg.rs:599-631), then SHA-256
 //   k_hh_final    one lane per key chain: folding, the two vector digests and the digest of the 16640-character
 //                 proof string (protocol.rs:121-175)
@@ -501,44 +501,59 @@ __global__ __launch_bounds__(1024) void k_hh_support(const uint8_t *__restrict__
 
 // ------------------------------------------------------------------------------------------ proof chain of the main key
 // pi <- pi ^ H'(pi ^ tilde_pi_x) for x = 0 .. N-1.  H' (mmo_hash4to4) hashes its four 16-byte blocks independently, so
-// the chain is four independent block chains: four lanes per key chain, no exchange until the final SHA-256.  A step is
-// one AES on the critical path and the kernel is bound by the issue latency of a lone wavefront, not by throughput.
-__global__ __launch_bounds__(256) void k_hh_chain(const uint8_t *__restrict__ keys, uint64_t stride, uint32_t n, uint32_t depth,
-                                                  const HhTables *__restrict__ tab, const uint4 *__restrict__ tpc,
-                                                  uint32_t *__restrict__ proofblk, const int32_t *__restrict__ status) {
+// the chain is four independent block chains, and a step is one AES on the critical path: the kernel is bound by the
+// latency of that AES, not by throughput.  Sixteen lanes per key chain: lane 4 b + q carries column q of block b, a round is
+// four table reads per lane instead of sixteen, and the three other columns of the block come from the neighbours of the
+// quad by DPP (quad_perm rotations, no LDS).  Each lane keeps its own eleven round-key words.
+__device__ __forceinline__ uint32_t quad_rot(uint32_t x, int by) {          // x of lane (q + by) % 4 of this quad
+    if (by == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x39, 0xf, 0xf, false);   // quad_perm:[1,2,3,0]
+    if (by == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4e, 0xf, 0xf, false);   // quad_perm:[2,3,0,1]
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x93, 0xf, 0xf, false);                // quad_perm:[3,0,1,2]
+}
+__device__ __forceinline__ uint32_t mmo_quad(const TabRef &R, const uint32_t (&rkq)[11], uint32_t in) {
+    uint32_t s = in ^ rkq[0];
+#pragma unroll
+    for (int r = 1; r < 10; r++) {
+        const uint32_t s1 = quad_rot(s, 1), s2 = quad_rot(s, 2), s3 = quad_rot(s, 3);
+        s = xor3(xor3(te<4>(R, 0, s, 0), te<4>(R, 1, s1, 8), te<4>(R, 2, s2, 16)), te<4>(R, 3, s3, 24), rkq[r]);
+    }
+    const uint32_t s1 = quad_rot(s, 1), s2 = quad_rot(s, 2), s3 = quad_rot(s, 3);
+    s = ((te<4>(R, 2, s, 0) & 0xff) | (te<4>(R, 3, s1, 8) & 0xff00) | (te<4>(R, 0, s2, 16) & 0xff0000) | (te<4>(R, 1, s3, 24) & 0xff000000)) ^ rkq[10];
+    return s ^ in;
+}
+__global__ __launch_bounds__(1024) void k_hh_chain(const uint8_t *__restrict__ keys, uint64_t stride, uint32_t n, uint32_t depth,
+                                                   const HhTables *__restrict__ tab, const uint4 *__restrict__ tpc,
+                                                   uint32_t *__restrict__ proofblk, const int32_t *__restrict__ status) {
     extern __shared__ uint32_t Tall[];   // the four AES tables, 128 KiB
     const uint32_t tid = threadIdx.x;
-    fill_table<TAIL_NT>(Tall, tab, tid, 256);
+    fill_table<TAIL_NT>(Tall, tab, tid, blockDim.x);
     __syncthreads();
     const TabRef T = tab_ref(Tall, tid);
-    const uint64_t g = (uint64_t)blockIdx.x * 256 + tid;
-    const uint64_t i = g >> 2;
-    const uint32_t b = (uint32_t)g & 3;
-    const bool live = i < n && status[i] == 0;
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + tid;
+    const uint64_t i = g >> 4;
+    const uint32_t w = (uint32_t)g & 15, q = w & 3;          // word w of the 64-byte proof: block w / 4, column q
+    const bool live = i < n && status[i] == 0;               // uniform over the 16 lanes of a key chain
     const HhLayout L(depth);
-    const uint32_t *rk1 = tab->rk[1];
     const uint32_t N = 1u << depth;
-    B128 pi = {{0, 0, 0, 0}};
-    if (live) {
-        pi = ldb128(keys + i * stride + L.cs + 16 * b);
-        const uint4 *tp = tpc + i * N * 4 + b;
-        uint4 nx = tp[0];
+    uint32_t rkq[11];
+#pragma unroll
+    for (int r = 0; r < 11; r++) rkq[r] = tab->rk[1][4 * r + q];
+    uint32_t pi = 0;
+    if (live) pi = ldb32(keys + i * stride + L.cs + 4 * w);
+    // every lane runs the loop (DPP needs its quad active); a dead key chain reads row 0 of key chain 0 and is never stored
+    const uint32_t *tp = reinterpret_cast<const uint32_t *>(tpc) + (live ? i : 0) * N * 16 + w;
+    uint32_t nx = tp[0];
 #pragma unroll 1
-        for (uint32_t x = 0; x < N; x++) {
-            const B128 hin = {{pi.w[0] ^ nx.x, pi.w[1] ^ nx.y, pi.w[2] ^ nx.z, pi.w[3] ^ nx.w}};
-            if (x + 1 < N) nx = tp[(x + 1) * 4];
-            const B128 ho = mmo<TAIL_NT>(T, rk1, hin);
-            pi.w[0] ^= ho.w[0]; pi.w[1] ^= ho.w[1]; pi.w[2] ^= ho.w[2]; pi.w[3] ^= ho.w[3];
-        }
+    for (uint32_t x = 0; x < N; x++) {
+        const uint32_t hin = pi ^ nx;
+        if (x + 1 < N) nx = tp[(x + 1) * 16];
+        pi ^= mmo_quad(T, rkq, hin);
     }
-    // gather the four blocks in the first lane of the quad
+    // gather the sixteen words in the first lane of the group
     uint32_t all[16];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) all[4 * q + k] = __shfl(pi.w[k], (int)((tid & 60) + q), 64);
-    }
-    if (live && b == 0) sha_of_pi_hex(all, proofblk + i * (HH_SUPPORT + 1) * 16);
+    for (int k = 0; k < 16; k++) all[k] = __shfl(pi, (int)((tid & 48) + k), 64);
+    if (live && w == 0) sha_of_pi_hex(all, proofblk + i * (HH_SUPPORT + 1) * 16);
 }
 
 // ------------------------------------------------------------------------------------------ folding and the tag
@@ -662,7 +677,14 @@ int launch_hh_chain(const uint8_t *d_keys, uint64_t stride, uint32_t n, uint32_t
                     const int32_t *d_status, hipStream_t stream) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_hh_chain), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TAIL_LDS);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k_hh_chain, dim3((uint32_t)((4ull * n + 255) / 256)), dim3(256), TAIL_LDS, stream, d_keys, stride, n, depth, d_tab, w.tpc, w.proofblk, d_status);
+    // one round of workgroups over the chip: as many lanes per workgroup as that takes (the tables are 128 KiB, one workgroup per CU)
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint64_t lanes = 16ull * n;
+    uint32_t threads = (uint32_t)(((lanes + cus - 1) / cus + 255) / 256 * 256);
+    threads = threads < 256 ? 256 : threads > 1024 ? 1024 : threads;
+    hipLaunchKernelGGL(k_hh_chain, dim3((uint32_t)((lanes + threads - 1) / threads)), dim3(threads), TAIL_LDS, stream, d_keys, stride, n, depth, d_tab, w.tpc,
+                       w.proofblk, d_status);
     return (int)hipGetLastError();
 }
 int launch_hh_final(const uint8_t *d_keys, uint64_t stride, uint32_t n, uint32_t depth, const HhWork &w, uint8_t *d_tags,
