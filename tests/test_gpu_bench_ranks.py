@@ -1,0 +1,43 @@
+"""bench.py's world > 1 branch on the GPU: two ranks share the one card (gloo rendezvous, because RCCL refuses two ranks on one
+device), each verifies its own shard of the reports through the C ABI, the partial aggregates are combined and the line carries
+the whole job.  The RCCL form of the combine (wh_comm_init / wh_prio3_allgather_reduce_dev) is the same branch with world = 1
+in tests/test_gpu_api_state.py; RCCL over two GPUs has not run anywhere yet."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(world, extra):
+    env = dict(os.environ, WH_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout            # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_one_gpu_prio3():
+    one = _run(1, ["--workload", "histogram", "--reports-per-gpu", "3000"])
+    two = _run(2, ["--workload", "histogram", "--reports-per-gpu", "3000"])
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "weak"
+    assert two["config"]["reports_per_gpu"] == 3000 and two["config"]["status_nonzero"] == 0
+    # whole-job value: both shards counted (the two ranks share one card, so no speed-up is asserted)
+    assert two["value"] > 0 and abs(two["value"] * two["ms_per_step"] * 1e-3 - 2 * 3000) < 1
+    assert abs(one["value"] * one["ms_per_step"] * 1e-3 - 3000) < 1
+    assert two["roofline"]["bound"] in ("valu", "hbm") and "cpu_baseline" not in two
