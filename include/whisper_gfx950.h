@@ -145,6 +145,30 @@ int32_t wh_prio3_prepare_init_batch(wh_ctx *ctx, const uint8_t verify_key[16], c
 int32_t wh_prio3_prepare_finish_batch(wh_ctx *ctx, const uint8_t *const *prep_shares, uint64_t n, uint8_t *prep_msgs,
                                       int32_t *status);
 
+/* ---- Prio3Count = Prio3<Count<Field64>, XofShake128, 16> (batched-flpcp-rs/src/vdaf/prio3.rs:81; flp/types.rs:39-105; Field64:
+ * fp.rs:359-389): the reference's Field64 instantiation, un-batched draft-07 preparation for a whole batch.  Any context will do
+ * (wh_hh_ctx_create is the cheapest); the state lives beside the context's other batches.  Elements are 8 bytes, little endian.
+ * replaces: both maps of server-base-prio3's run_vdaf_prepare (src/main.rs:41-61, 68-100) and its merge loop, for a server
+ * built with Prio3::new_count(num_aggregators).
+ *   blob / offsets: n encoded VdafKey<Prio3Count> (vdaf.rs:209-233): agg_id u8 | input share | nonce[16]; input share:
+ *     aggregator 0: meas[1] | proof[5] (48 bytes); others: measurement-share seed | proof-share seed (32 bytes).  There is no
+ *     public share and no blind (joint_rand_len = 0).
+ *   prep_shares: n * 32 bytes, the verifier share (Prio3PrepareShare without a joint-randomness part, prio3.rs:1953-1970).
+ *   status: WH_ERR_SHORT / WH_ERR_AGG_ID / WH_ERR_MODULUS / WH_ERR_QUERY_RAND where the reference's unwrap() would panic.
+ * finish: prep_shares[a] = aggregator a's n prepare shares; sums them, Type::decide (flp.rs:483-512); the prepare message is
+ *   empty for Count, so there is no output besides status (WH_ERR_DECIDE for rejected reports, WH_ERR_MODULUS for a
+ *   non-canonical share element).  aggregate: the mod-p sum of the out shares of accepted, kept reports (8 bytes). */
+int32_t wh_prio3_count_prepare_init_batch(wh_ctx *ctx, uint32_t num_aggregators, const uint8_t verify_key[16], const uint8_t *blob,
+                                          const uint64_t *offsets, uint64_t n, uint8_t *prep_shares, int32_t *status);
+int32_t wh_prio3_count_prepare_finish_batch(wh_ctx *ctx, uint32_t num_aggregators, const uint8_t *const *prep_shares, uint64_t n,
+                                            int32_t *status);
+int32_t wh_prio3_count_out_shares(wh_ctx *ctx, uint8_t *out_shares);            /* n * 8 bytes */
+int32_t wh_prio3_count_aggregate(wh_ctx *ctx, const uint8_t *keep, uint8_t agg[8]);
+/* test hooks: the Field64 sampler (prng.rs:73-99 on 8-byte chunks) with any bound; out: n rows of 5 words */
+int32_t wh_test_f64_xof_expand(wh_ctx *ctx, const uint8_t *seeds, uint32_t n, uint32_t usage, const uint8_t *binder, uint32_t binder_len,
+                               uint32_t n_elems, uint64_t bound, uint64_t *out);
+int32_t wh_prio3_count_set_test_sampler_bound(wh_ctx *ctx, uint64_t bound);     /* 0 = p */
+
 /* ---- the flp::Type surface (batched-flpcp-rs/src/flp.rs:186-196) ---- */
 /* replaces: Type::query (flp.rs:359-479) for n independent (input, proof, query_rand, joint_rand) tuples, all of this
  * context's circuit; HOST buffers of n rows each: input[input_len], proof[proof_len], query_rand[1],

@@ -162,4 +162,15 @@ int wo_aes_backend(void); /* 1 = AES-NI, 0 = portable */
 #ifdef __cplusplus
 }
 #endif
+/* ---- Prio3Count over Field64 (count64.c; prio3.rs:81, flp/types.rs:39-105) ---- */
+int wo_count_shard(uint32_t num_aggregators, uint64_t meas, const uint8_t nonce[16], const uint8_t *rand, uint8_t *leader_share,
+                   uint8_t *helper_shares);
+int wo_count_prepare_init(uint32_t num_aggregators, const uint8_t verify_key[16], uint32_t agg_id, const uint8_t nonce[16],
+                          const uint8_t *input_share, size_t input_share_len, uint8_t prep_share[32], uint8_t out_share[8]);
+int wo_count_prepare_init_encoded(uint32_t num_aggregators, const uint8_t verify_key[16], const uint8_t *key, size_t key_len,
+                                  uint8_t prep_share[32], uint8_t out_share[8]);
+int wo_count_prepare_finish(uint32_t num_aggregators, const uint8_t *prep_shares);
+void wo_count_aggregate(const uint8_t *out_shares, uint64_t n, const uint8_t *keep, uint8_t agg[8]);
+void wo_f64_expand(const uint8_t seed[16], uint32_t usage, const uint8_t *binder, size_t binder_len, uint64_t *out, size_t n);
+
 #endif

@@ -290,3 +290,49 @@ def hh_eval_and_check_batch(depth, verify_key, keys, nthreads=1, want_dat=True):
                                          status.ctypes.data)
     assert rc == 0, rc
     return dat, tags, ids, status
+
+
+# ---- Prio3Count over Field64 (oracle/count64.c) ----
+P64 = 2**64 - 2**32 + 1
+
+
+def count_shard(num_aggregators, meas, nonce, rand):
+    ls = _buf(48); hs = _buf(32 * (num_aggregators - 1))
+    rc = _lib.wo_count_shard(C.c_uint32(num_aggregators), C.c_uint64(meas), _b(nonce), _b(rand), ls, hs); assert rc == 0, rc
+    hs = bytes(hs)
+    return [bytes(ls)] + [hs[32 * i:32 * i + 32] for i in range(num_aggregators - 1)]
+
+
+def count_prepare_init(num_aggregators, verify_key, agg_id, nonce, input_share):
+    prep = _buf(32); out = _buf(8)
+    rc = _lib.wo_count_prepare_init(C.c_uint32(num_aggregators), _b(verify_key), C.c_uint32(agg_id), _b(nonce), _b(input_share),
+                                    C.c_size_t(len(input_share)), prep, out)
+    return rc, bytes(prep), bytes(out)
+
+
+def count_prepare_init_encoded(num_aggregators, verify_key, key):
+    prep = _buf(32); out = _buf(8)
+    rc = _lib.wo_count_prepare_init_encoded(C.c_uint32(num_aggregators), _b(verify_key), _b(key) if len(key) else _buf(1),
+                                            C.c_size_t(len(key)), prep, out)
+    return rc, bytes(prep), bytes(out)
+
+
+def count_prepare_finish(num_aggregators, prep_shares):
+    """0 accept, 1 reject, < 0 decode error; prep_shares: one 32-byte share per aggregator"""
+    return _lib.wo_count_prepare_finish(C.c_uint32(num_aggregators), _b(b"".join(prep_shares)))
+
+
+def count_aggregate(out_shares, keep=None):
+    n = len(out_shares)
+    agg = _buf(8)
+    k = None if keep is None else _b(bytes(bytearray(int(x) for x in keep)))
+    _lib.wo_count_aggregate.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    _lib.wo_count_aggregate(_b(b"".join(out_shares)) if n else None, n, k, agg)
+    return bytes(agg)
+
+
+def f64_expand(seed, usage, binder, n):
+    out = (C.c_uint64 * n)()
+    _lib.wo_f64_expand.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    _lib.wo_f64_expand(_b(seed), usage, _b(binder) if binder else None, len(binder), out, n)
+    return list(out)

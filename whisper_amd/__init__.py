@@ -12,5 +12,6 @@ from .prio3 import (  # noqa: F401
 )
 from .grouptest import general_binary_split_test, ClientProofTag  # noqa: F401
 from . import hh  # noqa: F401,E402
+from .count import Prio3Count, new_count  # noqa: F401,E402
 
 SORT_NOALLOC_MAX_N = 1 << 20   # WH_SORT_NOALLOC_MAX_N of include/whisper_gfx950.h

@@ -45,6 +45,8 @@ EXPORTS = [
     "wh_hh_aggregate", "wh_hh_aggregate_dev", "wh_hh_gen_key_chain", "wh_flp_prove_batch", "wh_client_shard_many_gpu", "wh_sort_by_testing_id_dev", "wh_sort_by_testing_id", "wh_keep_mask_dev",
     "wh_sort_by_testing_id_noalloc_dev", "wh_hh_bucket_sum_f128_dev", "wh_hh_bucket_accumulate_f128_dev", "wh_hh_eval_and_sketch_batch_dev", "wh_hh_sketch_subtract_dev", "wh_ctx_lock", "wh_ctx_unlock", "wh_host_alloc", "wh_host_free", "wh_comm_unique_id", "wh_comm_init", "wh_comm_destroy", "wh_comm_rank",
     "wh_prio3_allgather_reduce_dev", "wh_f128_allgather_reduce_dev", "wh_prio3_allgather_reduce", "wh_hh_allreduce_u32_dev",
+    "wh_prio3_count_prepare_init_batch", "wh_prio3_count_prepare_finish_batch", "wh_prio3_count_out_shares", "wh_prio3_count_aggregate",
+    "wh_test_f64_xof_expand", "wh_prio3_count_set_test_sampler_bound",
 ]
 
 vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32
@@ -75,6 +77,12 @@ lib.wh_prio3_prepare_init_batch_dev.argtypes = [vp, vp, vp, vp, u64, vp, vp]
 lib.wh_prio3_prepare_init_batch.argtypes = [vp, vp, vp, vp, u64, vp, vp]
 lib.wh_prio3_prepare_finish_batch.argtypes = [vp, vp, u64, vp, vp]
 lib.wh_test_f64_op.argtypes = [vp, i32, vp, vp, vp, u64]
+lib.wh_prio3_count_prepare_init_batch.argtypes = [vp, u32, vp, vp, vp, u64, vp, vp]
+lib.wh_prio3_count_prepare_finish_batch.argtypes = [vp, u32, vp, u64, vp]
+lib.wh_prio3_count_out_shares.argtypes = [vp, vp]
+lib.wh_prio3_count_aggregate.argtypes = [vp, vp, vp]
+lib.wh_test_f64_xof_expand.argtypes = [vp, vp, u32, u32, vp, u32, u32, u64, vp]
+lib.wh_prio3_count_set_test_sampler_bound.argtypes = [vp, u64]
 lib.wh_flp_query_batch.argtypes = [vp, vp, vp, vp, vp, u32, u64, vp, vp]
 lib.wh_flp_decide_batch.argtypes = [vp, vp, u64, vp]
 lib.wh_flp_encode.argtypes = [C.POINTER(Params), vp, vp]
