@@ -94,6 +94,17 @@ def test_count64_batches_vs_oracle(na):
         keep = good.astype(np.uint8)
         total = sum(int.from_bytes(s.aggregate(keep).tobytes(), "little") for s in servers) % P64
         assert total == int(meas[good].sum())
+        # offsets that descend or point past the blob: empty keys, not reads outside the blob
+        import ctypes as C
+        ks = [bytes(k) for k in keys[0][:4]]
+        blob = np.frombuffer(b"".join(ks) + b"\0", np.uint8)
+        off = np.zeros(5, np.uint64); off[1:] = np.cumsum([len(k) for k in ks])
+        off[2] = 1 << 40                                   # key 1 ends and key 2 starts far outside
+        prep = np.zeros((4, 32), np.uint8); st = np.zeros(4, np.int32)
+        vkb = np.frombuffer(vk, np.uint8)
+        assert W.lib.wh_prio3_count_prepare_init_batch(servers[0]._ctx, na, vkb.ctypes.data, blob.ctypes.data, off.ctypes.data, 4,
+                                                       prep.ctypes.data, st.ctypes.data) == 0
+        assert list(st) == [0, -2, -2, 0] and prep[0].tobytes() == O.count_prepare_init_encoded(na, vk, ks[0])[1]
         # empty batch, then state errors
         p0, s0 = servers[0].prepare_init_encoded_keys(vk, [])
         assert p0.shape == (0, 32) and servers[0].aggregate().tobytes() == bytes(8)

@@ -71,13 +71,14 @@ __device__ __forceinline__ void sample64(SpongeG &s, uint64_t (&out)[N], uint32_
 __device__ __forceinline__ uint64_t poly3(const uint64_t *c, uint64_t x) { return g_add(g_mul(g_add(g_mul(c[2], x), c[1]), x), c[0]); }
 
 // replaces: VdafKey::decode_with_param + Prio3::prepare_init + the out share of prepare_next, per report
-__global__ void __launch_bounds__(256) k_count_init(const uint8_t *blob, const uint64_t *offsets, uint32_t n, uint32_t num_aggregators,
+__global__ void __launch_bounds__(256) k_count_init(const uint8_t *blob, const uint64_t *offsets, uint64_t total, uint32_t n, uint32_t num_aggregators,
                                                     uint64_t vk0, uint64_t vk1, uint64_t bound, uint8_t *prep, uint64_t *out_shares,
                                                     int32_t *status) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint8_t *rep = blob + offsets[i];
-    const uint64_t len = offsets[i + 1] >= offsets[i] ? offsets[i + 1] - offsets[i] : 0;
+    // a descending pair, or one that points past the blob, is an empty key (WH_ERR_SHORT), never a read outside the blob
+    const uint64_t len = offsets[i + 1] >= offsets[i] && offsets[i + 1] <= total ? offsets[i + 1] - offsets[i] : 0;
     int32_t st = WH_OK;
     uint32_t agg = 0;
     if (len < 1) st = WH_ERR_SHORT;
@@ -206,7 +207,7 @@ Count64 *state_of(wh_ctx *c) {
     return static_cast<Count64 *>(*slot);
 }
 
-int32_t count_init_dev(wh_ctx *c, Count64 *S, uint32_t na, const uint8_t vk[16], const uint8_t *d_blob, const uint64_t *d_off, uint64_t n,
+int32_t count_init_dev(wh_ctx *c, Count64 *S, uint32_t na, const uint8_t vk[16], const uint8_t *d_blob, const uint64_t *d_off, uint64_t total, uint64_t n,
                        uint8_t *d_prep, int32_t *d_status) {
     int32_t rc;
     if ((rc = c_ensure(c, S->d_out, S->out_cap, n ? n : 1))) return rc;
@@ -214,7 +215,7 @@ int32_t count_init_dev(wh_ctx *c, Count64 *S, uint32_t na, const uint8_t vk[16],
     uint64_t k0, k1;
     memcpy(&k0, vk, 8); memcpy(&k1, vk + 8, 8);
     if (n) {
-        hipLaunchKernelGGL(k_count_init, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx_stream(c), d_blob, d_off, (uint32_t)n, na, k0, k1, S->bound,
+        hipLaunchKernelGGL(k_count_init, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx_stream(c), d_blob, d_off, total, (uint32_t)n, na, k0, k1, S->bound,
                            d_prep, S->d_out, d_status);
         C_HIPCHK(c, hipGetLastError());
     }
@@ -253,7 +254,7 @@ int32_t wh_prio3_count_prepare_init_batch(wh_ctx *c, uint32_t num_aggregators, c
         C_HIPCHK(c, hipMemcpyAsync(S->d_blob, blob, nbytes, hipMemcpyHostToDevice, st));
         C_HIPCHK(c, hipMemcpyAsync(S->d_off, offsets, 8 * (n + 1), hipMemcpyHostToDevice, st));
     }
-    if ((rc = count_init_dev(c, S, num_aggregators, verify_key, S->d_blob, S->d_off, n, S->d_prep, S->d_status))) return rc;
+    if ((rc = count_init_dev(c, S, num_aggregators, verify_key, S->d_blob, S->d_off, nbytes, n, S->d_prep, S->d_status))) return rc;
     if (n) {
         C_HIPCHK(c, hipMemcpyAsync(prep_shares, S->d_prep, 32 * n, hipMemcpyDeviceToHost, st));
         C_HIPCHK(c, hipMemcpyAsync(status, S->d_status, 4 * n, hipMemcpyDeviceToHost, st));
