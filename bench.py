@@ -204,10 +204,12 @@ def main():
     lanes = [Lane(vdaf)] + [Lane(W.Prio3(params, device=local_rank)) for _ in range(max(1, args.in_flight) - 1)]
     # N > 1: the combine goes through the library's own RCCL binding (wh_comm_init / wh_prio3_allgather_reduce_dev); the gloo
     # rehearsal (several ranks on one GPU, which RCCL refuses) keeps torch's all-gather + wh_f128_sum_rows_dev
-    wh_comm = world > 1 and backend == "nccl"
+    wh_comm, wh_comm_why = world > 1 and backend == "nccl", ""
     if wh_comm:
-        for ln in lanes:
-            comm_init_from_torch(ln.vdaf)
+        wh_comm, wh_comm_why = try_wh_comm([ln.vdaf for ln in lanes], dev,
+                                           lambda v: allgather_reduce_dev(v, lanes[0].agg.data_ptr(), lanes[0].total.data_ptr()))
+        if not wh_comm and rank == 0:
+            print(f"bench.py: falling back to torch.distributed for the combine ({wh_comm_why})", file=sys.stderr)
     d_status = lanes[0].status
     torch.cuda.synchronize()
     bad_ids = []
@@ -326,6 +328,8 @@ def main():
                        "leader_report_bytes": s.leader_report_len, "helper_report_bytes": s.helper_report_len,
                        "roles": "alternating Leader/Helper", "inputs": "resident in HBM", "batches_in_flight": len(lanes), "sort_and_keep_mask_in_step": bool(args.with_sort),
                        "parallelism": f"reports sharded over {world} GPU(s); all-gather + mod-p reduce of partial aggregates",
+                       "combine": ("none (one GPU)" if world == 1 else "wh_comm: the library's RCCL binding (wh_prio3_allgather_reduce_dev)" if wh_comm
+                                   else f"torch.distributed all_gather ({backend}) + wh_f128_sum_rows_dev" + (f"; wh_comm unavailable: {wh_comm_why}" if wh_comm_why else "")),
                        "status_nonzero": n_bad_status, "client_gen_s": round(t_gen, 2),
                        "gpu_shard_clients_per_s": round(n / t_shard) if t_shard else None},
             "roofline": roofline_obj(dom, kernels, meas_perms, meas_ms, achieved, traffic, traffic_src, avg_ms, bytes_per_launch, launches),
@@ -347,6 +351,39 @@ def main():
     for ln in lanes:
         ln.vdaf.close()
     return result
+
+
+def try_wh_comm(objs, dev, trial):
+    """Bind the contexts to the library's own RCCL communicator (wh_comm_init) and run one trial collective.  Every rank
+    reports whether that worked; unless all did, every rank falls back to torch.distributed's collective (also RCCL) followed by
+    the on-GPU reduction -- the combine is the same arithmetic either way, and a rank must never wait on a collective that
+    another rank has given up on.  Returns (use_wh_comm, why_not)."""
+    import torch.distributed as dist
+
+    def all_ok(flag):
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+    why = ""
+    try:
+        from whisper_amd.dist import comm_unique_id
+        comm_unique_id()                      # does RCCL load in this process at all?
+        ok = True
+    except Exception as e:                    # noqa: BLE001
+        ok, why = False, f"RCCL binding: {e}"
+    if not all_ok(ok):
+        return False, why or "RCCL binding failed on another rank"
+    try:
+        for o in objs:
+            comm_init_from_torch(o)
+            trial(o)
+            o.synchronize()
+        ok = True
+    except Exception as e:                    # noqa: BLE001
+        ok, why = False, f"wh_comm_init / trial collective: {e}"
+    if not all_ok(ok):
+        return False, why or "wh_comm_init failed on another rank"
+    return True, ""
 
 
 def roofline_obj(dom, kernels, meas_perms, meas_ms, hbm_achieved, traffic, traffic_src, avg_ms, bytes_per_launch, launches):
@@ -448,9 +485,12 @@ def bench_hh(args, rank, local_rank, world, dev, backend):
     keys[:, :8] = ((rank << 40) + np.arange(n, dtype=np.uint64) % clients).view(np.uint8).reshape(n, 8)   # client ids
     h = hh.HeavyHitters(N, device=local_rank)
     ext = torch.cuda.ExternalStream(h.stream, device=dev)
-    wh_comm = world > 1 and backend == "nccl"            # the library's own RCCL binding; the gloo rehearsal keeps torch's
+    wh_comm, wh_comm_why = world > 1 and backend == "nccl", ""   # the library's own RCCL binding; the gloo rehearsal keeps torch's
+    d_trial = torch.zeros(64, dtype=torch.int32, device=dev)
     if wh_comm:
-        comm_init_from_torch(h)
+        wh_comm, wh_comm_why = try_wh_comm([h], dev, lambda o: hh_allreduce_u32_dev(o, d_trial.data_ptr(), 64))
+        if not wh_comm and rank == 0:
+            print(f"bench.py: falling back to torch.distributed for the combine ({wh_comm_why})", file=sys.stderr)
     d_keys = torch.from_numpy(keys).to(dev)
     d_dat = torch.empty((n, N, 258), dtype=torch.int32, device=dev) if os.environ.get("WH_BENCH_HH_MATERIALIZE") else None
     d_tags = torch.zeros((n, 64), dtype=torch.uint8, device=dev)
@@ -543,7 +583,9 @@ def bench_hh(args, rank, local_rank, world, dev, backend):
             "config": {"workload": wl["desc"], "clients_per_gpu": clients, "repetitions": reps, "buckets": N,
                        "key_chains_per_step_per_gpu": n, "key_chain_bytes": ln, "distinct_key_chains_tiled": K,
                        "inputs": "resident in HBM", "status_nonzero": n_bad_status, "client_gen_s": round(t_gen, 2),
-                       "parallelism": f"key chains sharded over {world} GPU(s); integer all-reduce of the sketches"},
+                       "parallelism": f"key chains sharded over {world} GPU(s); integer all-reduce of the sketches",
+                       "combine": ("none (one GPU)" if world == 1 else "wh_comm: the library's RCCL binding (wh_hh_allreduce_u32_dev)" if wh_comm
+                                   else f"torch.distributed all_reduce ({backend})" + (f"; wh_comm unavailable: {wh_comm_why}" if wh_comm_why else ""))},
             "roofline": {"bound": "lds", "kernel": "k_hh_main", "achieved": main_blocks / (main_ms * 1e-3) / 1e9, "peak": aes_peak / 1e9,
                          "unit": "G AES-128 blocks/s", "frac": main_blocks / (main_ms * 1e-3) / aes_peak, "traffic": traffic,
                          "peak_derivation": "table AES: 176 ds_read_b32 per block at 32 lanes/clk/CU = 111.7 G blocks/s at 2.4 GHz; instruction "
