@@ -277,6 +277,18 @@ struct LazySmall {
 };
 WH_HD void f_small_zero(LazySmall &a) { a.c[0] = a.c[1] = a.c[2] = a.c[3] = 0; }
 WH_HD void f_small_mac(LazySmall &a, const F128 &x, uint32_t s) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(WH_SMALL_MAC_PLAIN)
+    // one multiply-add per word: left to itself hipcc turns a power-of-two s into a 64-bit shift and a 64-bit add (two
+    // first-slot instructions instead of one)
+    asm("v_mad_u64_u32 %0, vcc, %4, %8, %0\n\t"
+        "v_mad_u64_u32 %1, vcc, %5, %8, %1\n\t"
+        "v_mad_u64_u32 %2, vcc, %6, %8, %2\n\t"
+        "v_mad_u64_u32 %3, vcc, %7, %8, %3"
+        : "+v"(a.c[0]), "+v"(a.c[1]), "+v"(a.c[2]), "+v"(a.c[3])
+        : "v"((uint32_t)x.lo), "v"((uint32_t)(x.lo >> 32)), "v"((uint32_t)x.hi), "v"((uint32_t)(x.hi >> 32)), "v"(s)
+        : "vcc");
+    return;
+#endif
     a.c[0] += (uint64_t)(uint32_t)x.lo * s;
     a.c[1] += (uint64_t)(uint32_t)(x.lo >> 32) * s;
     a.c[2] += (uint64_t)(uint32_t)x.hi * s;
