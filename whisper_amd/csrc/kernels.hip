@@ -725,7 +725,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
                     WH_Q_ADV(p);
                 }
                 wires(jj + 4, false);
+#if !(defined(WH_Q_EXP) && WH_Q_EXP == 3)     // timing experiment (results invalid): no truncate tiles
                 if (lds_trunc) tile(jj + 4);
+#endif
             }
 #undef WH_Q_ADV
         } else {
