@@ -432,6 +432,17 @@ __global__ __launch_bounds__(1024) void k_hh_main(const uint8_t *__restrict__ ke
     }
 }
 
+// the same from a pointer known to be global memory: one unaligned load instruction (gfx950 global loads are byte-addressable)
+// instead of four or sixteen byte loads
+typedef uint32_t hh_u32_u1 __attribute__((aligned(1)));
+typedef uint32_t hh_u32x4 __attribute__((ext_vector_type(4)));
+typedef hh_u32x4 hh_u32x4_u1 __attribute__((aligned(1)));
+__device__ __forceinline__ uint32_t ldg32u(const uint8_t *p) { return *(const __attribute__((address_space(1))) hh_u32_u1 *)p; }
+__device__ __forceinline__ B128 ldg128u(const uint8_t *p) {
+    const hh_u32x4 t = *(const __attribute__((address_space(1))) hh_u32x4_u1 *)p;
+    return B128{{t.x, t.y, t.z, t.w}};
+}
+
 // ------------------------------------------------------------------------------------------ support keys
 // VDPFKey<u32>::eval_all::<bool>: one level, two leaves, hashed index x = false, true
 constexpr uint32_t SUP_THREADS = 1024, TAIL_NT = 4;
@@ -449,14 +460,19 @@ __global__ __launch_bounds__(1024) void k_hh_support(const uint8_t *__restrict__
     const uint32_t sup = (uint32_t)(g - i * HH_SUPPORT);
     const HhLayout L(depth);
     const uint8_t *p = keys + i * stride + L.sup + (uint64_t)HH_SUPPORT_LEN * sup;
-    const uint32_t kid = p[0];
-    const B128 root = ldb128(p + 1);
-    const B128 cw = ldb128(p + 25);
     if (status[i] != 0) return;  // rejected by k_hh_main (it checks every support key's header too)
+    // the 111 bytes of a support key as seven unaligned loads (byte-wise they were 101 load instructions per lane)
+    const uint32_t kid = p[0];
+    const B128 root = ldg128u(p + 1);
+    const B128 cw = ldg128u(p + 25);
     uint32_t cs[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) cs[k] = ldb32(p + 43 + 4 * k);
-    const uint32_t oc = ldb32(p + 107);
+    for (int q = 0; q < 4; q++) {
+        const B128 t = ldg128u(p + 43 + 16 * q);
+#pragma unroll
+        for (int k = 0; k < 4; k++) cs[4 * q + k] = t.w[k];
+    }
+    const uint32_t oc = ldg32u(p + 107);
     const uint32_t *rk0 = tab->rk[0], *rk1 = tab->rk[1];
 
     B128 c0 = {{root.w[0] & ~3u, root.w[1], root.w[2], root.w[3]}};
