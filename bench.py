@@ -277,6 +277,8 @@ def main():
     for k, (ms, cnt) in ktimes.items():
         if cnt:
             kernels[k] = {"ms_per_step": ms / args.steps, "launches_per_step": cnt / args.steps}
+            if k == "expand":
+                kernels[k]["overlapped"] = "side stream, beside k_meas: the event time includes the wait for free wave slots; not part of the step's sum"
             if k in per and ms > 0:      # algorithmic bytes of the step over the kernel's time: its own HBM roofline figure
                 kernels[k]["alg_gb_per_s"] = per[k] / (ms / args.steps * 1e-3) / 1e9
                 kernels[k]["hbm_frac"] = kernels[k]["alg_gb_per_s"] / HBM_PEAK_GBS
@@ -549,6 +551,8 @@ def bench_hh(args, rank, local_rank, world, dev, backend):
     result = None
     if rank == 0:
         kernels = {k: {"ms_per_step": ms / args.steps, "launches_per_step": cnt / args.steps} for k, (ms, cnt) in ktimes.items() if cnt}
+        if "hh_sum" in kernels and fused:
+            kernels["hh_sum"]["overlapped"] = "second stream, under k_hh_support / k_hh_chain / k_hh_final; not part of the step's sum"
         main_ms = kernels["hh_main"]["ms_per_step"]          # all launches of the step: the batch, and the rejected key chains again
         # k_hh_main per key chain: the key chain read, the corrected leaf hashes written; the bucket vectors are either
         # written (materialised path) or added into the L2-resident sketches (fused path: no HBM bytes per key chain)
