@@ -204,7 +204,7 @@ def main():
     lanes = [Lane(vdaf)] + [Lane(W.Prio3(params, device=local_rank)) for _ in range(max(1, args.in_flight) - 1)]
     # N > 1: the combine goes through the library's own RCCL binding (wh_comm_init / wh_prio3_allgather_reduce_dev); the gloo
     # rehearsal (several ranks on one GPU, which RCCL refuses) keeps torch's all-gather + wh_f128_sum_rows_dev
-    wh_comm, wh_comm_why = world > 1 and backend == "nccl", ""
+    wh_comm, wh_comm_why = world > 1 and backend == "nccl" and os.environ.get("WH_BENCH_COMBINE", "wh_comm") != "torch", ""
     if wh_comm:
         wh_comm, wh_comm_why = try_wh_comm([ln.vdaf for ln in lanes], dev,
                                            lambda v: allgather_reduce_dev(v, lanes[0].agg.data_ptr(), lanes[0].total.data_ptr()))
@@ -487,7 +487,8 @@ def bench_hh(args, rank, local_rank, world, dev, backend):
     keys[:, :8] = ((rank << 40) + np.arange(n, dtype=np.uint64) % clients).view(np.uint8).reshape(n, 8)   # client ids
     h = hh.HeavyHitters(N, device=local_rank)
     ext = torch.cuda.ExternalStream(h.stream, device=dev)
-    wh_comm, wh_comm_why = world > 1 and backend == "nccl", ""   # the library's own RCCL binding; the gloo rehearsal keeps torch's
+    # the library's own RCCL binding; the gloo rehearsal keeps torch's; WH_BENCH_COMBINE=torch forces torch.distributed's collective
+    wh_comm, wh_comm_why = world > 1 and backend == "nccl" and os.environ.get("WH_BENCH_COMBINE", "wh_comm") != "torch", ""
     d_trial = torch.zeros(64, dtype=torch.int32, device=dev)
     if wh_comm:
         wh_comm, wh_comm_why = try_wh_comm([h], dev, lambda o: hh_allreduce_u32_dev(o, d_trial.data_ptr(), 64))
