@@ -579,8 +579,11 @@ struct QueryShared {      // behind the weight rows in LDS
 
 // BASE: draft-07 prepare_init -- the verifier share itself is the output (`tags` then points at
 // the prepare shares, (verifier_len + 1) elements per report: verifier | own joint-rand part).
+#ifndef WH_Q_WAVES
+#define WH_Q_WAVES 3
+#endif
 template <bool HIST, bool BASE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_query_psum(Prio3Dev P, Workspace W, uint8_t *tags,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WH_Q_WAVES, WH_Q_WAVES))) k_query_psum(Prio3Dev P, Workspace W, uint8_t *tags,
                                                     uint8_t *out_shares, int32_t *status) {
     extern __shared__ uint32_t lds_w[];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, S = blockDim.x >> 6;
