@@ -324,6 +324,25 @@ int32_t wh_sort_by_testing_id(wh_ctx *ctx, const uint8_t *ids, uint64_t n, uint3
  * The mask then goes to wh_prio3_aggregate_dev / wh_hh_aggregate_dev.  Asynchronous: the ids are copied into pinned
  * staging owned by the context before the call returns, so bad_ids may be reused at once. */
 int32_t wh_keep_mask_dev(wh_ctx *ctx, const uint8_t *d_ids, uint64_t n, const uint8_t *bad_ids, uint64_t n_bad, uint8_t *d_keep);
+/* replaces: ClientProofTag::batch_proof / batch_proof_shake128 / batch_proof_sha256 (common/src/grouptest.rs:43-99) for k slices
+ * of ONE sorted tag list at a time -- the two calls per mismatching range of a group-test round (grouptest.rs:306-318).
+ * d_ids[n][16] (little-endian u128, ascending: the output of wh_sort_by_testing_id_dev) and d_tags[n][tag_bytes] (tag_bytes a
+ * multiple of 8: 16 for the Prio3 tags, 64 for the heavy-hitter proof strings) are device memory.  Slice i is the items
+ * [starts[i], ends[i]) (host arrays, ends[i] <= n); its proof covers the leading items with id <= uppers[i] (host, k x 16 bytes,
+ * little endian): counts[i] = their number (batch_proof's split index), proofs[i] = SHAKE128(verify_key || tags)[0..16] when
+ * proof_size = 16, SHA-256(verify_key || tags) when proof_size = 32 (host, k x proof_size bytes).  One GPU lane per slice: worth
+ * calling for tens of slices and more; one long slice (the complete proof of grouptest.rs:143) is faster on a host core.
+ * Synchronous. */
+int32_t wh_grouptest_batch_proofs_dev(wh_ctx *ctx, const uint8_t *d_ids, const uint8_t *d_tags, uint64_t n, uint32_t tag_bytes,
+                                      const uint8_t *verify_key, const uint64_t *starts, const uint64_t *ends, const uint8_t *uppers,
+                                      uint32_t k, uint32_t proof_size, uint8_t *proofs, uint64_t *counts);
+/* replaces: the loop over the d initial ranges (common/src/grouptest.rs:182-208), whose slice i starts where slice i - 1
+ * stopped: proofs[i], counts[i] as above for the items behind every id <= max(uppers[0..i-1]) with id <= uppers[i];
+ * firsts[i] = index of the slice's first item (the reference's `slice_so_far`).  All d slices are found (binary search) and
+ * hashed side by side.  Synchronous. */
+int32_t wh_grouptest_split_proofs_dev(wh_ctx *ctx, const uint8_t *d_ids, const uint8_t *d_tags, uint64_t n, uint32_t tag_bytes,
+                                      const uint8_t *verify_key, const uint8_t *uppers, uint32_t d, uint32_t proof_size, uint8_t *proofs,
+                                      uint64_t *firsts, uint64_t *counts);
 
 int32_t wh_ctx_synchronize(wh_ctx *ctx);
 

@@ -43,7 +43,7 @@ EXPORTS = [
     "wh_test_f64_op", "wh_flp_query_batch", "wh_flp_decide_batch", "wh_flp_encode", "wh_flp_prove", "wh_hh_bucket_accumulate_u32_dev", "wh_prio3_prepare_init_batch_dev", "wh_prio3_prepare_init_batch", "wh_prio3_prepare_finish_batch",
     "wh_hh_key_chain_len", "wh_hh_ctx_create", "wh_hh_eval_and_check_batch_dev", "wh_hh_eval_and_check_batch", "wh_hh_buckets",
     "wh_hh_aggregate", "wh_hh_aggregate_dev", "wh_hh_gen_key_chain", "wh_flp_prove_batch", "wh_client_shard_many_gpu", "wh_sort_by_testing_id_dev", "wh_sort_by_testing_id", "wh_keep_mask_dev",
-    "wh_sort_by_testing_id_noalloc_dev", "wh_hh_bucket_sum_f128_dev", "wh_hh_bucket_accumulate_f128_dev", "wh_hh_eval_and_sketch_batch_dev", "wh_hh_sketch_subtract_dev", "wh_ctx_lock", "wh_ctx_unlock", "wh_host_alloc", "wh_host_free", "wh_comm_unique_id", "wh_comm_init", "wh_comm_destroy", "wh_comm_rank",
+    "wh_sort_by_testing_id_noalloc_dev", "wh_grouptest_batch_proofs_dev", "wh_grouptest_split_proofs_dev", "wh_hh_bucket_sum_f128_dev", "wh_hh_bucket_accumulate_f128_dev", "wh_hh_eval_and_sketch_batch_dev", "wh_hh_sketch_subtract_dev", "wh_ctx_lock", "wh_ctx_unlock", "wh_host_alloc", "wh_host_free", "wh_comm_unique_id", "wh_comm_init", "wh_comm_destroy", "wh_comm_rank",
     "wh_prio3_allgather_reduce_dev", "wh_f128_allgather_reduce_dev", "wh_prio3_allgather_reduce", "wh_hh_allreduce_u32_dev",
     "wh_prio3_count_prepare_init_batch", "wh_prio3_count_prepare_finish_batch", "wh_prio3_count_out_shares", "wh_prio3_count_aggregate",
     "wh_test_f64_xof_expand", "wh_prio3_count_set_test_sampler_bound",
@@ -96,6 +96,8 @@ lib.wh_sort_by_testing_id_dev.argtypes = [vp, vp, u64, vp, vp, u32, vp, vp]
 lib.wh_sort_by_testing_id.argtypes = [vp, vp, u64, vp]
 lib.wh_sort_by_testing_id_noalloc_dev.argtypes = [vp, vp, u64, vp, vp, u32, vp, vp]
 lib.wh_keep_mask_dev.argtypes = [vp, vp, u64, vp, u64, vp]
+lib.wh_grouptest_batch_proofs_dev.argtypes = [vp, vp, vp, u64, u32, vp, vp, vp, vp, u32, u32, vp, vp]
+lib.wh_grouptest_split_proofs_dev.argtypes = [vp, vp, vp, u64, u32, vp, vp, u32, u32, vp, vp, vp]
 lib.wh_host_alloc.argtypes = [u64, C.POINTER(vp)]
 lib.wh_host_free.argtypes = [vp]
 lib.wh_ctx_lock.argtypes = [vp]

@@ -102,6 +102,7 @@ struct wh_ctx {
     std::recursive_mutex mu;
     void *comm = nullptr;        // multi-GPU state (comm.hip)
     void *count = nullptr;       // Prio3Count / Field64 state (count64.hip)
+    void *grouptest = nullptr;   // job and result staging of the batch-proof kernel (grouptest.hip)
     double k_ms[WH_NUM_KERNELS] = {0};
     uint64_t k_launches[WH_NUM_KERNELS] = {0};
     std::string err;
@@ -272,6 +273,8 @@ hipStream_t ctx_stream(wh_ctx *c) { return c->stream; }
 void **ctx_comm_slot(wh_ctx *c) { return &c->comm; }
 void **ctx_count_slot(wh_ctx *c) { return &c->count; }
 void count64_free(void *state);
+void **ctx_grouptest_slot(wh_ctx *c) { return &c->grouptest; }
+void grouptest_free(void *state);
 std::recursive_mutex &ctx_mutex(wh_ctx *c) { return c->mu; }
 void ctx_set_error(wh_ctx *c, const std::string &what) { c->err = what; }
 uint32_t ctx_output_len(wh_ctx *c) { return c->z.output_len; }
@@ -352,6 +355,7 @@ void wh_ctx_destroy(wh_ctx *c) {
     wh_comm_destroy(c);
     if (c->stream) hipStreamSynchronize(c->stream);
     wh::count64_free(c->count); c->count = nullptr;
+    wh::grouptest_free(c->grouptest); c->grouptest = nullptr;
     if (c->stream2) hipStreamSynchronize(c->stream2);
     void *ptrs[] = {c->d_omega, c->d_stab, c->d_aes, c->d_out_shares, c->d_status_own, c->d_status_keep, c->d_tmp_a, c->d_tmp_b, c->d_tmp_c, c->d_keep_eff, c->d_partials,
                     c->d_blob, c->d_offsets, c->d_tags, c->d_ids, c->d_prep, c->W.desc, c->W.scal, c->W.weights, c->W.wlimbs, c->W.pows, c->W.rlc,
