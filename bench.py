@@ -378,13 +378,20 @@ def try_wh_comm(objs, dev, trial):
     try:
         for o in objs:
             comm_init_from_torch(o)
+        ok = True
+    except Exception as e:                    # noqa: BLE001
+        ok, why = False, f"wh_comm_init: {e}"
+    if not all_ok(ok):                        # before anyone enters a collective that a failed rank will never join
+        return False, why or "wh_comm_init failed on another rank"
+    try:
+        for o in objs:
             trial(o)
             o.synchronize()
         ok = True
     except Exception as e:                    # noqa: BLE001
-        ok, why = False, f"wh_comm_init / trial collective: {e}"
+        ok, why = False, f"trial collective: {e}"
     if not all_ok(ok):
-        return False, why or "wh_comm_init failed on another rank"
+        return False, why or "trial collective failed on another rank"
     return True, ""
 
 
