@@ -279,6 +279,9 @@ def main():
             kernels[k] = {"ms_per_step": ms / args.steps, "launches_per_step": cnt / args.steps}
             if k == "expand":
                 kernels[k]["overlapped"] = "side stream, beside k_meas: the event time includes the wait for free wave slots; not part of the step's sum"
+            if k == "hash" and not os.environ.get("WH_HASH_B_MAIN") and not os.environ.get("WH_NO_SIDE_STREAM"):
+                kernels[k]["note"] = ("job A (joint / query randomness, barycentric weights) only; job B (hash of the public parts, "
+                                      "RLC coefficients, testing ids) runs on the side stream beside k_meas, untimed")
             if k in per and ms > 0:      # algorithmic bytes of the step over the kernel's time: its own HBM roofline figure
                 kernels[k]["alg_gb_per_s"] = per[k] / (ms / args.steps * 1e-3) / 1e9
                 kernels[k]["hbm_frac"] = kernels[k]["alg_gb_per_s"] / HBM_PEAK_GBS

@@ -196,7 +196,10 @@ __device__ __forceinline__ void weights_and_tables(const Prio3Dev &P, const Work
 #define WH_HASH_PREFETCH false
 #endif
 #ifndef WH_HASH_ATTR
-#define WH_HASH_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
+#ifndef WH_HASH_WAVES
+#define WH_HASH_WAVES 3
+#endif
+#define WH_HASH_ATTR __attribute__((amdgpu_waves_per_eu(WH_HASH_WAVES, WH_HASH_WAVES)))
 #endif
 // Job A (lanes [0, npad)): five sponges (the own joint-rand part, prio3.rs:2543-2555, comes from
 //   k_meas) -- joint-rand
