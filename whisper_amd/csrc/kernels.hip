@@ -146,13 +146,13 @@ __device__ __forceinline__ void weights_and_tables(const Prio3Dev &P, const Work
         L[j] = acc;
         acc = f_mul(acc, f_sub(r, P.omega[j]));
     }
-    F128 inv = f_inv(acc);
-    F128 k = f_mul(f_sub(rm, f_one()), P.m_inv);
+    // the common factor (r^m - 1)/m rides on the running inverse: three multiplications per weight
+    F128 inv = f_mul(f_inv(acc), f_mul(f_sub(rm, f_one()), P.m_inv));
     for (uint32_t j = P.n_weights; j-- > 0;) {
         F128 w = P.omega[j];
-        F128 dinv = f_mul(inv, L[j]);          // 1 / (r - w^j)
+        F128 dinv = f_mul(inv, L[j]);          // (r^m - 1)/m / (r - w^j)
         inv = f_mul(inv, f_sub(r, w));
-        L[j] = f_mul(f_mul(k, w), dinv);
+        L[j] = f_mul(w, dinv);
     }
     if (P.circuit != CIRCUIT_AVERAGE) {
         // what the query kernel would otherwise compute with a whole wavefront per value:
