@@ -332,7 +332,7 @@ int32_t wh_keep_mask_dev(wh_ctx *ctx, const uint8_t *d_ids, uint64_t n, const ui
  * little endian): counts[i] = their number (batch_proof's split index), proofs[i] = SHAKE128(verify_key || tags)[0..16] when
  * proof_size = 16, SHA-256(verify_key || tags) when proof_size = 32 (host, k x proof_size bytes).  One GPU lane per slice: worth
  * calling for tens of slices and more; one long slice (the complete proof of grouptest.rs:143) is faster on a host core.
- * Synchronous. */
+ * k <= 2^24 slices per call.  Synchronous. */
 int32_t wh_grouptest_batch_proofs_dev(wh_ctx *ctx, const uint8_t *d_ids, const uint8_t *d_tags, uint64_t n, uint32_t tag_bytes,
                                       const uint8_t *verify_key, const uint64_t *starts, const uint64_t *ends, const uint8_t *uppers,
                                       uint32_t k, uint32_t proof_size, uint8_t *proofs, uint64_t *counts);

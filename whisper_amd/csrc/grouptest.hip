@@ -145,6 +145,7 @@ __global__ void __launch_bounds__(64) k_batch_proofs(const uint8_t *ids, const u
     }
 }
 
+constexpr uint32_t GT_MAX_SLICES = 1u << 24;     // per call; the staging is 160 bytes per slice
 struct GtState {
     GtJob *d_jobs = nullptr, *h_jobs = nullptr;
     GtOut *d_out = nullptr, *h_out = nullptr;
@@ -226,7 +227,7 @@ int32_t wh_grouptest_batch_proofs_dev(wh_ctx *c, const uint8_t *d_ids, const uin
                                       uint32_t k, uint32_t proof_size, uint8_t *proofs, uint64_t *counts) {
     if (!gt_params_ok(c, d_ids, d_tags, n, tag_bytes, verify_key, proof_size)) return WH_ERR_PARAM;
     if (k == 0) return WH_OK;
-    if (!starts || !ends || !uppers || !proofs || !counts) return WH_ERR_PARAM;
+    if (k > GT_MAX_SLICES || !starts || !ends || !uppers || !proofs || !counts) return WH_ERR_PARAM;
     std::lock_guard<std::recursive_mutex> lk(ctx_mutex(c));
     for (uint32_t i = 0; i < k; i++)
         if (starts[i] > ends[i] || ends[i] > n) { ctx_set_error(c, "wh_grouptest_batch_proofs_dev: slice outside the list"); return WH_ERR_PARAM; }
@@ -248,7 +249,7 @@ int32_t wh_grouptest_split_proofs_dev(wh_ctx *c, const uint8_t *d_ids, const uin
                                       uint64_t *firsts, uint64_t *counts) {
     if (!gt_params_ok(c, d_ids, d_tags, n, tag_bytes, verify_key, proof_size)) return WH_ERR_PARAM;
     if (d == 0) return WH_OK;
-    if (!uppers || !proofs || !firsts || !counts) return WH_ERR_PARAM;
+    if (d > GT_MAX_SLICES || !uppers || !proofs || !firsts || !counts) return WH_ERR_PARAM;
     std::lock_guard<std::recursive_mutex> lk(ctx_mutex(c));
     // slice i starts where slice i - 1 stopped: behind the ids <= the largest bound so far
     unsigned __int128 prev = 0, run_max = 0;
