@@ -1091,14 +1091,23 @@ int32_t wh_f128_sum_rows_dev(wh_ctx *c, const uint8_t *d_rows, uint64_t n_rows, 
 }
 
 // acc[words] += sum of the kept rows of buckets[n][words] (no zeroing), on stream st
-static int32_t hh_sum_on(wh_ctx *c, hipStream_t st, const uint32_t *d_buckets, const uint8_t *d_keep, uint64_t n, uint64_t words, uint32_t *d_acc) {
+// `beside`: the launch shares the chip with the heavy-hitter proof kernels on the main stream, which are chains of latencies
+// with few wavefronts (k_hh_final: 219 for 14 000 key chains).  Left alone, the sums' 4 000 workgroups per launch fill every
+// wave slot and those kernels' workgroups wait behind them (k_hh_final 1.0 -> 2.2 ms).  Here every workgroup asks for
+// 120 KiB of LDS it does not use: one per CU, four wavefronts with eight vectors in flight per lane; the sums then take
+// 3.0 instead of 2.2 ms, still under the proof kernels, and those run at their own pace (profiles/r2d_bench_hh_*.json).
+static int32_t hh_sum_on(wh_ctx *c, hipStream_t st, const uint32_t *d_buckets, const uint8_t *d_keep, uint64_t n, uint64_t words, uint32_t *d_acc,
+                         bool beside = false) {
     if (!n) return WH_OK;
+    static const uint32_t beside_lds = getenv("WH_HH_SUM_LDS") ? (uint32_t)atoi(getenv("WH_HH_SUM_LDS")) : 120u << 10;
     const uint32_t gx = (uint32_t)((words + 4 * 256 - 1) / (4 * 256));
     // enough (x, y) blocks to fill the chip: target ~4096 blocks
     uint32_t gy = 4096 / gx; if (gy < 1) gy = 1; if (gy > n) gy = (uint32_t)n; if (gy > 65535) gy = 65535;
     const uint32_t cpb = (uint32_t)((n + gy - 1) / gy);
     gy = (uint32_t)((n + cpb - 1) / cpb);
-    hipLaunchKernelGGL(k_hh_sum_u32, dim3(gx, gy), dim3(256), 0, st, d_buckets, d_keep, n, words, cpb, d_acc);
+    if (beside && beside_lds)
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_hh_sum_u32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)beside_lds));
+    hipLaunchKernelGGL(k_hh_sum_u32, dim3(gx, gy), dim3(256), beside ? beside_lds : 0, st, d_buckets, d_keep, n, words, cpb, d_acc);
     HIPCHK(c, hipGetLastError());
     return WH_OK;
 }
@@ -1223,7 +1232,7 @@ static int32_t hh_eval(wh_ctx *c, const uint8_t verify_key[16], const uint8_t *d
             KTimer t_(c, WH_K_HH, c->stream2);
             for (uint64_t lo = base; lo < base + m;) {           // the stretch of each sketch inside this sub-batch
                 const uint64_t g = lo / group_size, hi = std::min<uint64_t>(base + m, (g + 1) * group_size);
-                if ((rc = hh_sum_on(c, c->stream2, c->d_hh_part + (lo - base) * words, nullptr, hi - lo, words, d_sketch + g * words))) return rc;
+                if ((rc = hh_sum_on(c, c->stream2, c->d_hh_part + (lo - base) * words, nullptr, hi - lo, words, d_sketch + g * words, true))) return rc;
                 lo = hi;
             }
             HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));

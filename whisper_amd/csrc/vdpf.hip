@@ -426,13 +426,14 @@ __global__ __launch_bounds__(1024) void k_hh_support(const uint8_t *__restrict__
     fill_table<TAIL_NT>(Tall, tab, tid, SUP_THREADS);
     __syncthreads();
     const TabRef T = tab_ref(Tall, tid);
-    const uint64_t g = (uint64_t)blockIdx.x * SUP_THREADS + tid;
-    if (g >= (uint64_t)n * HH_SUPPORT) return;
+    const HhLayout L(depth);
+    // persistent workgroups (one per CU: the tables are filled once, not once per 1024 keys)
+#pragma unroll 1
+    for (uint64_t g = (uint64_t)blockIdx.x * SUP_THREADS + tid; g < (uint64_t)n * HH_SUPPORT; g += (uint64_t)gridDim.x * SUP_THREADS) {
     const uint64_t i = g / HH_SUPPORT;
     const uint32_t sup = (uint32_t)(g - i * HH_SUPPORT);
-    const HhLayout L(depth);
     const uint8_t *p = keys + i * stride + L.sup + (uint64_t)HH_SUPPORT_LEN * sup;
-    if (status[i] != 0) return;  // rejected by k_hh_main (it checks every support key's header too)
+    if (status[i] != 0) continue;  // rejected by k_hh_main (it checks every support key's header too)
     // the 111 bytes of a support key as seven unaligned loads (byte-wise they were 101 load instructions per lane)
     const uint32_t kid = p[0];
     const B128 root = ldg128u(p + 1);
@@ -485,6 +486,7 @@ __global__ __launch_bounds__(1024) void k_hh_support(const uint8_t *__restrict__
     supd[g * 2] = d[0];
     supd[g * 2 + 1] = d[1];
     sha_of_pi_hex(pi, proofblk + (i * (HH_SUPPORT + 1) + 1 + sup) * 16);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ proof chain of the main key
@@ -657,7 +659,12 @@ int launch_hh_support(const uint8_t *d_keys, uint64_t stride, uint32_t n, uint32
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_hh_support), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TAIL_LDS);
     if (e != hipSuccess) return (int)e;
     const uint64_t sup_threads = (uint64_t)n * HH_SUPPORT;
-    hipLaunchKernelGGL(k_hh_support, dim3((uint32_t)((sup_threads + SUP_THREADS - 1) / SUP_THREADS)), dim3(SUP_THREADS), TAIL_LDS, stream, d_keys, stride, n,
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    uint64_t groups = (sup_threads + SUP_THREADS - 1) / SUP_THREADS;
+    if (groups > (uint64_t)cus) groups = cus;
+    if (!groups) groups = 1;
+    hipLaunchKernelGGL(k_hh_support, dim3((uint32_t)groups), dim3(SUP_THREADS), TAIL_LDS, stream, d_keys, stride, n,
                        depth, d_tab, w.proofblk, w.supd, d_status);
     return (int)hipGetLastError();
 }
