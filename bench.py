@@ -378,6 +378,30 @@ def try_wh_comm(objs, dev, trial):
         ok, why = False, f"RCCL binding: {e}"
     if not all_ok(ok):
         return False, why or "RCCL binding failed on another rank"
+    # The library's communicator over more than one GPU is code that no test box could run.  Rehearse it in child processes
+    # first: one per rank, own unique id, two small collectives, a time limit.  A child that hangs is killed and every rank
+    # takes the torch.distributed path; a rank that hung inside its own communicator could only be killed from outside.
+    import subprocess
+    box = [comm_unique_id().hex() if dist.get_rank() == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "wh_comm_probe.py")
+    limit = float(os.environ.get("WH_BENCH_PROBE_SECONDS", "120"))
+    try:
+        child = subprocess.Popen([sys.executable, probe, box[0], str(dist.get_rank()), str(dist.get_world_size()), str(dev.index or 0)],
+                                 stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        try:
+            _, err = child.communicate(timeout=limit)
+            ok = child.returncode == 0
+            if not ok:
+                why = f"rehearsal child exited {child.returncode}: {err.decode(errors='replace').strip().splitlines()[-1:]}"
+        except subprocess.TimeoutExpired:
+            child.kill()
+            child.communicate()
+            ok, why = False, f"rehearsal child did not finish within {limit:.0f} s"
+    except OSError as e:
+        ok, why = False, f"rehearsal child: {e}"
+    if not all_ok(ok):
+        return False, why or "the rehearsal of the library's communicator failed on another rank"
     try:
         for o in objs:
             comm_init_from_torch(o)
