@@ -123,7 +123,10 @@ template <int NT> __device__ __forceinline__ void aes_round_mix(const uint32_t (
 // block's XORs and rotates under the sixteen reads of the other.  With four tables the same order costs 4 % (7.2 -> 7.5 ms;
 // all 32 reads ahead of all XORs: 7.7), so that layout keeps the compiler's order.
 template <int NT> __device__ __forceinline__ void mmo2(const TabRef &R, const uint32_t *__restrict__ rk, const B128 &ia, const B128 &ib, B128 &oa, B128 &ob) {
-    if constexpr (NT == 2) {
+#ifndef WH_HH_FIXED_ORDER_NT4
+#define WH_HH_FIXED_ORDER_NT4 0
+#endif
+    if constexpr (NT == 2 || (NT == 4 && WH_HH_FIXED_ORDER_NT4)) {
         uint32_t a[4], b[4], ta[16], tb[16];
 #pragma unroll
         for (int k = 0; k < 4; k++) { a[k] = ia.w[k] ^ rk[k]; b[k] = ib.w[k] ^ rk[k]; }
