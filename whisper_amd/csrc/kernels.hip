@@ -758,10 +758,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WH_Q_W
         }
         // this lane's slot: seeds (call 0), differences against the public proof, RLC
         if (k < P.chunk) {
+            // every load of this block first, in one go: left to the compiler they sit in front of their uses, one memory
+            // latency after the other (six per slot block)
+            F128 s_even = ld128g(d.proof2 + 16ull * (2 * k)), s_odd = ld128g(d.proof2 + 16ull * (2 * k + 1));
+            F128 q_even = f_zero(), q_odd = f_zero(), c_even = f_zero(), c_odd = f_zero();
+            if (!BASE) {
+                q_even = ld128g(pp1 + 16ull * (1 + 2 * k)); q_odd = ld128g(pp1 + 16ull * (2 + 2 * k));
+                c_even = ld128g(reinterpret_cast<const uint8_t *>(rlc + 1 + 2 * k)); c_odd = ld128g(reinterpret_cast<const uint8_t *>(rlc + 2 + 2 * k));
+            }
+            __builtin_amdgcn_sched_barrier(0);
             const F128 A = f_add(Af, f_lazy_reduce(cA));
             const F128 B = f_add(Bf, f_lazy_reduce(cB));
             const F128 rk = f_mul(rho_lane, rho_kb);                                    // rho^(k + 1)
-            F128 s_even = ld128g(d.proof2 + 16ull * (2 * k)), s_odd = ld128g(d.proof2 + 16ull * (2 * k + 1));
             bad |= !f_in_range(s_even.lo, s_even.hi) | !f_in_range(s_odd.lo, s_odd.hi);
             F128 v_even = f_add(f_mul(L0, s_even), f_mul(rk, A));
             F128 v_odd = f_sub(f_add(f_mul(L0, s_odd), B), h_sumL);
@@ -769,10 +777,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WH_Q_W
                 ver_row[1 + 2 * k] = v_even;
                 ver_row[2 + 2 * k] = v_odd;
             } else {
-                F128 q_even = ld128g(pp1 + 16ull * (1 + 2 * k)), q_odd = ld128g(pp1 + 16ull * (2 + 2 * k));
                 bad |= !f_in_range(q_even.lo, q_even.hi) | !f_in_range(q_odd.lo, q_odd.hi);
                 if (leader) { v_even = f_sub(v_even, q_even); v_odd = f_sub(v_odd, q_odd); }
-                tag = f_add(tag, f_add(f_mul(rlc[1 + 2 * k], v_even), f_mul(rlc[2 + 2 * k], v_odd)));
+                tag = f_add(tag, f_add(f_mul(c_even, v_even), f_mul(c_odd, v_odd)));
             }
         }
         if (kb + 64 * S < P.chunk) rho_kb = f_mul(rho_kb, pw->rho64[S]);
@@ -800,22 +807,35 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WH_Q_W
         f_lazy_zero(cv);
         F128 rpow = f_mul(pw->r_lo[lane & 7], pw->r_hi[lane >> 3]), r64 = pw->r64;
         uint32_t since = 0;
-        for (uint32_t e = lane; e < P.gpoly_len; e += 64) {
-            F128 c = ld128g(G + 16ull * e);
-            bad |= !f_in_range(c.lo, c.hi);
-            uint32_t cl[5], t1[5], t2[5];
-            f_split26(c, cl);
-            f_split26(rpow, t1);
-            f_split26(P.s_tab[e], t2);
-            f_lazy_mac(cg, cl, t1);
-            f_lazy_mac(cv, cl, t2);
-            rpow = f_mul(rpow, r64);
-            if (++since == LAZY_MAX_TERMS) {
-                g_at_r = f_add(g_at_r, f_lazy_reduce(cg));
-                v0 = f_add(v0, f_lazy_reduce(cv));
-                f_lazy_zero(cg);
-                f_lazy_zero(cv);
-                since = 0;
+        // eight coefficients (and their s-table entries) in flight per lane: one memory latency per 512 coefficients
+        for (uint32_t e0 = lane; e0 < P.gpoly_len; e0 += 512) {
+            F128 cc[8], ss[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t e = e0 + 64 * u, ec = e < P.gpoly_len ? e : 0;
+                cc[u] = ld128g(G + 16ull * ec);
+                ss[u] = P.s_tab[ec];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (e0 + 64 * u >= P.gpoly_len) break;
+                const F128 c = cc[u];
+                bad |= !f_in_range(c.lo, c.hi);
+                uint32_t cl[5], t1[5], t2[5];
+                f_split26(c, cl);
+                f_split26(rpow, t1);
+                f_split26(ss[u], t2);
+                f_lazy_mac(cg, cl, t1);
+                f_lazy_mac(cv, cl, t2);
+                rpow = f_mul(rpow, r64);
+                if (++since == LAZY_MAX_TERMS) {
+                    g_at_r = f_add(g_at_r, f_lazy_reduce(cg));
+                    v0 = f_add(v0, f_lazy_reduce(cv));
+                    f_lazy_zero(cg);
+                    f_lazy_zero(cv);
+                    since = 0;
+                }
             }
         }
         g_at_r = wave_sum(f_add(g_at_r, f_lazy_reduce(cg)));
@@ -830,17 +850,28 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WH_Q_W
                 F128 v = ld128g(d.proof1 + 16ull * e);
                 bad |= !f_in_range(v.lo, v.hi);
             }
+        // first and last element of both public proofs and this lane's first pair of each: eight loads in one go
+        const uint32_t k0 = lane < P.chunk ? lane : 0;
+        F128 fl[2][2], ab0[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const uint8_t *pp = t ? pp1 : pp0;
+            fl[t][0] = ld128g(pp); fl[t][1] = ld128g(pp + 16ull * (1 + P.arity));
+            ab0[t][0] = ld128g(pp + 16ull * (1 + 2 * k0)); ab0[t][1] = ld128g(pp + 16ull * (2 + 2 * k0));
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             const uint8_t *pp = t ? pp1 : pp0;
             F128 acc = f_zero();
             for (uint32_t kk = lane; kk < P.chunk; kk += 64) {
-                F128 a = ld128g(pp + 16ull * (1 + 2 * kk)), b = ld128g(pp + 16ull * (2 + 2 * kk));
+                F128 a = ab0[t][0], b = ab0[t][1];
+                if (kk != lane) { a = ld128g(pp + 16ull * (1 + 2 * kk)); b = ld128g(pp + 16ull * (2 + 2 * kk)); }
                 bad |= !f_in_range(a.lo, a.hi) | !f_in_range(b.lo, b.hi);
                 acc = f_add(acc, f_mul(a, b));
             }
             acc = wave_sum(acc);
-            F128 first = ld128g(pp), last = ld128g(pp + 16ull * (1 + P.arity));
+            F128 first = fl[t][0], last = fl[t][1];
             bad |= !f_in_range(first.lo, first.hi) | !f_in_range(last.lo, last.hi);
             bool ok = f_is_zero(first) && f_eq(acc, last);
             if (lane == 0) sh->dec[t] = ok ? f_zero() : f_one();
@@ -854,6 +885,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WH_Q_W
         sh->tag[wave] = tag;
         sh->sum_x[wave] = sx;
         sh->bad[wave] = bad;
+    }
+    // what the last step (one lane) multiplies: fetched ahead of the barrier instead of one latency per product behind it
+    const uint32_t vl_ = P.verifier_len;
+    F128 fin[9];
+    if (!BASE && wave == 0) {
+        fin[0] = ld128g(pp1); fin[1] = ld128g(pp1 + 16ull * (1 + P.arity));
+        fin[2] = rlc[0]; fin[3] = rlc[1 + P.arity];
+#pragma unroll
+        for (int q = 0; q < 5; q++) fin[4 + q] = rlc[vl_ + q];
     }
     __syncthreads();
     bad = 0;
@@ -878,17 +918,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WH_Q_W
             else { ver_row[0] = v0; ver_row[1 + P.arity] = g_at_r; if (P.ver_stride > vl) ver_row[vl] = sc->own; }
             return;
         }
-        F128 q0 = ld128g(pp1), qg = ld128g(pp1 + 16ull * (1 + P.arity));
+        F128 q0 = fin[0], qg = fin[1];
         F128 d0 = leader ? f_sub(v0, q0) : v0;
         F128 dg = leader ? f_sub(g_at_r, qg) : g_at_r;
-        tag = f_add(tag, f_mul(rlc[0], d0));
-        tag = f_add(tag, f_mul(rlc[1 + P.arity], dg));
-        tag = f_add(tag, f_mul(rlc[vl], sh->dec[0]));
-        tag = f_add(tag, f_mul(rlc[vl + 1], sh->dec[1]));
-        if (sc->rand_diff[0]) tag = f_add(tag, rlc[vl + 2]);
-        if (sc->rand_diff[1]) tag = f_add(tag, rlc[vl + 3]);
+        tag = f_add(tag, f_mul(fin[2], d0));
+        tag = f_add(tag, f_mul(fin[3], dg));
+        tag = f_add(tag, f_mul(fin[4], sh->dec[0]));
+        tag = f_add(tag, f_mul(fin[5], sh->dec[1]));
+        if (sc->rand_diff[0]) tag = f_add(tag, fin[6]);
+        if (sc->rand_diff[1]) tag = f_add(tag, fin[7]);
         F128 hs = leader ? f_neg(sc->hash) : sc->hash;       // prio3.rs:2844-2855
-        tag = f_add(tag, f_mul(rlc[vl + 4], hs));
+        tag = f_add(tag, f_mul(fin[8], hs));
         if (bad) { status[i] = ST_ERR_MODULUS; tag = f_zero(); }
         // prepare_encoded_key: the Helper-role tag is negated (main.rs:53-59)
         st128(tag_out, leader ? tag : f_neg(tag));
