@@ -190,10 +190,12 @@ __device__ __forceinline__ void weights_and_tables(const Prio3Dev &P, const Work
 }
 
 // ---------------------------------------------------------------------------------- hash ----
-// Three wavefronts a SIMD (168 VGPRs) and no register prefetch of the next rate block: the absorbs here are short, and the
-// third wavefront is worth more than the loads in flight (4.45 -> 3.65 ms at 125 000 reports; four wavefronts spill 59).
+// Three wavefronts a SIMD (168 VGPRs).  Register prefetch of the next rate block: it lost while jobs A and B shared one launch
+// (3 906 wavefronts: the third wavefront per SIMD was worth more than the loads in flight, 4.45 -> 3.65 ms at 125 000 reports);
+// since job B runs beside k_meas, job A alone is under two wavefronts per SIMD, every block's loads are exposed, and the
+// prefetch wins (3.17 -> 2.93 ms).
 #ifndef WH_HASH_PREFETCH
-#define WH_HASH_PREFETCH false
+#define WH_HASH_PREFETCH true
 #endif
 #ifndef WH_HASH_ATTR
 #ifndef WH_HASH_WAVES
