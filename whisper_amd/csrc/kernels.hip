@@ -148,9 +148,12 @@ __device__ __forceinline__ void weights_and_tables(const Prio3Dev &P, const Work
     }
     // the common factor (r^m - 1)/m rides on the running inverse: three multiplications per weight
     F128 inv = f_mul(f_inv(acc), f_mul(f_sub(rm, f_one()), P.m_inv));
+    F128 parked = L[P.n_weights - 1];          // the next prefix product is fetched a step ahead of its use
     for (uint32_t j = P.n_weights; j-- > 0;) {
         F128 w = P.omega[j];
-        F128 dinv = f_mul(inv, L[j]);          // (r^m - 1)/m / (r - w^j)
+        const F128 pre = parked;
+        if (j) parked = L[j - 1];
+        F128 dinv = f_mul(inv, pre);           // (r^m - 1)/m / (r - w^j)
         inv = f_mul(inv, f_sub(r, w));
         L[j] = f_mul(w, dinv);
     }
@@ -173,8 +176,11 @@ __device__ __forceinline__ void weights_and_tables(const Prio3Dev &P, const Work
         const F128 rc = f_pow_u32(rho, P.chunk);
         uint4 *wl = reinterpret_cast<uint4 *>(W.wlimbs + (uint64_t)i * 12 * P.calls);
         F128 pj = f_one(), sumL = f_zero();
+        F128 lnext = L[1];
         for (uint32_t j = 1; j <= P.calls; j++) {
-            const F128 l = L[j], m = f_mul(l, pj);
+            const F128 l = lnext;
+            if (j < P.calls) lnext = L[j + 1];
+            const F128 m = f_mul(l, pj);
             sumL = f_add(sumL, l);
             uint32_t tl[5], tm[5];
             f_split26(l, tl);
