@@ -101,6 +101,8 @@ int32_t wh_ctx_unlock(wh_ctx *ctx);
  *   tags        n*16   proof tags (already negated for Helper-role reports)
  *   testing_ids n*16   u128 LE
  *   status      n      int32 per report
+ * A report that does not decode (status != 0 from the parse: short, bad aggregator id, wrong num_queries) gets a zero tag, a
+ * zero testing id and a zero out share, whatever the buffers held before.
  * The out shares (truncated measurement shares) stay in the context for wh_prio3_aggregate*. */
 int32_t wh_prio3_prepare_batch_dev(wh_ctx *ctx, const uint8_t verify_key[16], const uint8_t *d_blob,
                                    const uint64_t *d_offsets, uint64_t n, uint8_t *d_tags,

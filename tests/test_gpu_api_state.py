@@ -44,11 +44,13 @@ def test_descending_offset_pair_is_a_short_report_not_a_wild_read():
     vdaf = W.Prio3(p)
     try:
         d_blob, d_off, d_tags, d_ids, d_status = device_inputs(alice, broken)
+        d_tags.fill_(0xa5); d_ids.fill_(0x5a)             # what a reused buffer holds: a malformed report's tag and id are zero all the same
         vdaf.prepare_batch_dev(VK, d_blob.data_ptr(), d_off.data_ptr(), n, d_tags.data_ptr(), d_ids.data_ptr(), d_status.data_ptr())
         vdaf.synchronize()
         status = d_status.cpu().numpy()
         tags = d_tags.cpu().numpy().reshape(n, 16)
         assert status[7] == WH_ERR_SHORT and not tags[7].any()
+        assert not d_ids.cpu().numpy().reshape(n, 16)[7].any()
         good = [i for i in range(n) if i not in (7, 8)]
         o_tags, o_ids, o_status, _ = O.prio3_prepare_batch(O.params(*CFG), VK, blob, off, nthreads=2)
         assert not status[good].any()

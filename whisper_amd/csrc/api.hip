@@ -436,7 +436,7 @@ static int32_t prepare_range(wh_ctx *c, const PrepPlan &pl, const uint8_t *d_blo
         HIPCHK(c, hipMemsetAsync(c->W.counters, 0, 64, c->stream));
         { KTimer t_(c, WH_K_PARSE);
         hipLaunchKernelGGL(k_parse, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, d_blob, d_off + r, nb,
-                           d_status + base, tags_b, out_b); }
+                           d_status + base, tags_b, d_ids + 16 * base, out_b); }
         // side stream: the Helpers' proof shares and the hash kernel's job B (hash of the public parts, RLC coefficients,
         // testing ids).  Both are independent of k_meas and run in the wave slots it leaves; what then remains between
         // k_meas and the query kernel is job A alone (3.9 -> 3.2 ms on the critical path, +0.3 ms in k_meas).

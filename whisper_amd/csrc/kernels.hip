@@ -70,7 +70,7 @@ __device__ __forceinline__ bool report_of_slot(const Workspace &W, uint32_t slot
 // agg_id, num_queries.  Field-element range checks happen where the elements are loaded
 // (query kernel).  Trailing bytes are not looked at (server-batch-prio3/src/main.rs:46-47).
 __global__ void k_parse(Prio3Dev P, Workspace W, const uint8_t *blob, const uint64_t *offsets, uint32_t n,
-                        int32_t *status, uint8_t *tags, uint8_t *out_shares) {
+                        int32_t *status, uint8_t *tags, uint8_t *testing_ids, uint8_t *out_shares) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint8_t *rep = blob + offsets[i];
@@ -123,6 +123,7 @@ __global__ void k_parse(Prio3Dev P, Workspace W, const uint8_t *blob, const uint
         F128 *out_row = reinterpret_cast<F128 *>(out_shares) + (uint64_t)i * P.output_len;
         for (uint32_t e = 0; e < P.output_len; e++) out_row[e] = f_zero();
         st128(tags + 16ull * i, f_zero());
+        st128(testing_ids + 16ull * i, f_zero());      // k_hash skips the report: without this the id is whatever the buffer held
     }
     W.desc[i] = d;
     status[i] = st;
