@@ -113,6 +113,38 @@ def test_key_format_errors_and_padding():
     h.close()
 
 
+def test_device_entry_overwrites_stale_outputs():
+    """Caller-owned output buffers that held something else before the call (a reused allocation): every tag, testing id,
+    status and bucket vector of the batch is written, for well-formed and malformed key chains alike, and equals the oracle's."""
+    import torch
+    from whisper_amd import hh
+    depth, n = 3, 8
+    vk = bytes(range(3, 19))
+    A, _, _, _ = _make(depth, n, 17)
+    ln = A.shape[1]
+    K = A.copy()
+    K[1, 16] = 2                       # key_id is not a bool
+    K[4, 41 + 18 * depth + 64] = 1     # Bucket.data length
+    K[6, ln - 111 * 200] = 7           # a support key's key_id
+    h = hh.HeavyHitters(1 << depth)
+    dev = torch.device("cuda:0")
+    d_keys = torch.from_numpy(K).to(dev)
+    d_dat = torch.full((n, 1 << depth, 258), 0x5a5a5a5a, dtype=torch.int32, device=dev)
+    d_tags = torch.full((n, 64), 0xa5, dtype=torch.uint8, device=dev)
+    d_ids = torch.full((n, 16), 0x3c, dtype=torch.uint8, device=dev)
+    d_status = torch.full((n,), 77, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    h.eval_and_check_dev(vk, d_keys.data_ptr(), ln, n, d_dat.data_ptr(), d_tags.data_ptr(), d_ids.data_ptr(), d_status.data_ptr())
+    h.synchronize()
+    odat, otags, oids, ostatus = o.hh_eval_and_check_batch(depth, vk, K, nthreads=4)
+    assert [int(x) for x in ostatus] == [0, -9, 0, 0, -9, 0, -9, 0]
+    assert (d_status.cpu().numpy() == ostatus).all()
+    assert (d_tags.cpu().numpy() == otags).all()
+    assert (d_ids.cpu().numpy() == oids).all()
+    assert (d_dat.cpu().numpy().view(np.uint32) == odat).all()
+    h.close()
+
+
 def test_sub_batches_and_device_entry(monkeypatch):
     """The device-pointer entry point with caller-owned buffers; WH_HH_SUBBATCH makes the 300 key chains take five
     sub-batches of scratch (the last one partial), more workgroups than CUs walk the persistent loop, and the sum runs in
