@@ -589,9 +589,10 @@ def bench_hh(args, rank, local_rank, world, dev, backend):
         if "hh_sum" in kernels and fused:
             kernels["hh_sum"]["overlapped"] = "second stream, under k_hh_support / k_hh_chain / k_hh_final; not part of the step's sum"
         main_ms = kernels["hh_main"]["ms_per_step"]          # all launches of the step: the batch, and the rejected key chains again
-        # k_hh_main per key chain: the key chain read, the corrected leaf hashes written; the bucket vectors are either
-        # written (materialised path) or added into the L2-resident sketches (fused path: no HBM bytes per key chain)
-        main_bytes = n * (ln + (0 if fused else 4 * words) + 64 * N + 4 * 258 + 20) + (len(bad_index) * ln if fused else 0)
+        # k_hh_main per key chain: the key chain read, the corrected leaf hashes and the bucket vector written -- into the caller's
+        # array (materialised path) or into the context's sub-batch scratch, which k_hh_sum_u32 reads back on the second stream
+        # (sketch path); the rejected key chains are read once more and go into the sketch by atomics
+        main_bytes = n * (ln + 4 * words + 64 * N + 4 * 258 + 20) + (len(bad_index) * ln if fused else 0)
         # AES blocks the algorithm needs per key chain: tree, leaf hashes, 65 counters per leaf, proof chain,
         # 14 per support key, testing id; in k_hh_main: all but the chain and the support keys
         aes_all = 2 * (N - 1) + 2 * N + 65 * N + 4 * N + 257 * 14 + 1
@@ -630,7 +631,9 @@ def bench_hh(args, rank, local_rank, world, dev, backend):
                          "peak_derivation": "table AES: 176 ds_read_b32 per block at 32 lanes/clk/CU = 111.7 G blocks/s at 2.4 GHz; instruction "
                                             "issue (VALU and LDS instructions of a SIMD do not overlap) 119.7 G blocks/s; the lower binds",
                          "ms_per_step_all_launches": main_ms, "aes_blocks_per_step": main_blocks,
-                         "sketch_sum": "fused into the expansion (atomic adds into per-XCD partial sketches)" if fused else "materialised, then k_hh_sum_u32",
+                         "sketch_sum": ("wh_hh_eval_and_sketch_batch_dev: a sub-batch's bucket vectors in a context scratch, summed by k_hh_sum_u32 on a second "
+                                        "stream under the proof kernels; rejected key chains re-expanded and subtracted (atomic adds)") if fused
+                                       else "materialised by the caller, then k_hh_sum_u32 per repetition",
                          "hbm": {"achieved": main_bytes / (main_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": main_bytes / (main_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                                  "alg_bytes_per_step": main_bytes}},

@@ -41,3 +41,13 @@ def test_bench_two_ranks_one_gpu_prio3():
     assert two["value"] > 0 and abs(two["value"] * two["ms_per_step"] * 1e-3 - 2 * 3000) < 1
     assert abs(one["value"] * one["ms_per_step"] * 1e-3 - 3000) < 1
     assert two["roofline"]["bound"] in ("valu", "hbm") and "cpu_baseline" not in two
+
+
+def test_bench_two_ranks_one_gpu_heavy_hitters():
+    """The heavy-hitter workload's world > 1 branch: key chains sharded by rank, sketches combined by an integer all-reduce."""
+    two = _run(2, ["--workload", "hh_t0.01", "--reports-per-gpu", "8", "--unique", "16"])
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["unit"] == "key chains/s"
+    n = two["config"]["key_chains_per_step_per_gpu"]
+    assert n == 8 * two["config"]["repetitions"] and two["config"]["status_nonzero"] == 0
+    assert abs(two["value"] * two["ms_per_step"] * 1e-3 - 2 * n) < 1
+    assert two["roofline"]["bound"] == "lds" and "all_reduce" in two["config"]["combine"]
