@@ -5,7 +5,8 @@
  * This is the drop-in boundary.  The reference has no FFI seam of its own: the path sits behind
  * Rust traits, so each entry point below names the reference interface it replaces.  All
  * functions return an int32 status (0 = ok, negative = error), never throw, and take plain
- * pointers and sizes.  One context per GPU; a context is used by one thread at a time.
+ * pointers and sizes.  One context per GPU (or a few); threads may share a context: every entry point
+ * takes the context's lock while it works (wh_ctx_lock below for multi-call sequences).
  *
  * Encodings are the reference's own: reports are `VdafBatchedKey::get_encoded()` bytes
  * (batched-flpcp-rs/src/vdaf.rs:148-162), field elements are 16-byte little-endian canonical
@@ -193,6 +194,16 @@ int32_t wh_flp_prove_batch(wh_ctx *ctx, const uint8_t *input, const uint8_t *pro
 int32_t wh_flp_encode(const wh_prio3_params *params, const uint64_t *measurement, uint8_t *input);
 int32_t wh_flp_prove(const wh_prio3_params *params, const uint8_t *input, const uint8_t *prove_rand,
                      const uint8_t *joint_rand, uint8_t *proof);
+
+/* replaces: discrete_fourier_transform + discrete_fourier_transform_inv_finish (batched-flpcp-rs/src/fft.rs:31-85, 102-115), the
+ * transform under poly_fft / poly_interpret_eval (polynomial.rs:187-231) that Type::prove and Type::query call per wire, for n
+ * independent vectors: in[n][n_in] Field128 residues, zero-padded to `size` (a power of two, n_in <= size), out[n][size] with
+ * out[i] = sum_j in[j] w^(ij), w = the reference's primitive size-th root (fp.rs:391-421); inverse != 0: the same transform
+ * followed by inv_finish (scaled by 1/size, index i <-> size - i), i.e. interpolation.  Host buffers, synchronous.  An element
+ * >= p: WH_ERR_MODULUS; size > 2^20 (the reference's MAX_ROOTS): WH_ERR_PARAM; size > 4096: WH_ERR_UNSUPPORTED (one
+ * workgroup holds a vector and its twiddles in LDS).  The product path does not call it (the prover fuses its transforms,
+ * the verifier evaluates in barycentric form): it is the stand-alone surface for parity against fft.rs. */
+int32_t wh_ntt_f128_batch(wh_ctx *ctx, const uint8_t *in, uint64_t n_in, uint64_t size, int32_t inverse, uint64_t n, uint8_t *out);
 
 /* ---- aggregation ---- */
 /* replaces: the merge loop over reports whose testing id is not in the bad set

@@ -140,3 +140,54 @@ def test_gpu_prove_matches_oracle(name, cfg):
         assert not st.any() and all(vdaf.flp_decide(ver))
     finally:
         vdaf.close()
+
+
+# ---- discrete_fourier_transform / inv_finish (fft.rs:31-115) as a stand-alone batch entry point ----
+def _elems(tag, n):
+    raw = bytes(det(tag.encode(), 16 * n + 16))
+    return [int.from_bytes(raw[16 * i:16 * i + 16], "little") % O.P128 for i in range(n)]
+
+
+@pytest.mark.parametrize("size,n_in", [(1, 1), (2, 2), (4, 3), (64, 64), (64, 17), (256, 129), (512, 512), (1024, 511), (4096, 4096), (8, 0)])
+def test_ntt_batch_matches_oracle_fft(size, n_in):
+    """wh_ntt_f128_batch against the oracle's restatement of fft.rs, forward and inverse, zero-padded inputs, and the algebra
+    the reference's own test checks (fft.rs:131-160): inverse(forward(x)) = x."""
+    vdaf = W.Prio3(W.Prio3Params(W.SUMVEC, 16, 16, 8))
+    try:
+        n = 3
+        rows = [_elems(f"ntt-{size}-{n_in}-{r}", n_in) for r in range(n)]
+        rows[1] = [O.P128 - 1] * n_in if n_in else []              # the largest residue everywhere
+        v = np.frombuffer(b"".join(O.f_enc(x) for row in rows for x in row), np.uint8).reshape(n, n_in, 16)
+        fwd = vdaf.ntt(v, size)
+        inv = vdaf.ntt(v, size, inverse=True)
+        for r in range(n):
+            assert [O.f_dec(fwd[r, i].tobytes()) for i in range(size)] == O.fft(rows[r], size)
+            assert [O.f_dec(inv[r, i].tobytes()) for i in range(size)] == O.fft(rows[r], size, inverse=True)
+        back = vdaf.ntt(fwd, size, inverse=True)
+        for r in range(n):
+            assert [O.f_dec(back[r, i].tobytes()) for i in range(size)] == rows[r] + [0] * (size - n_in)
+    finally:
+        vdaf.close()
+
+
+def test_ntt_batch_definition_and_errors():
+    """Against the definition out[i] = sum_j in[j] w^(ij) with Python integers (w = the reference's root for that size), and
+    the error classes: a non-canonical element, a size that is no power of two, more inputs than points, sizes past the limits."""
+    vdaf = W.Prio3(W.Prio3Params(W.HISTOGRAM, 0, 4, 2))
+    try:
+        size, n_in = 16, 11
+        x = _elems("ntt-def", n_in)
+        w = O.f_root(4)
+        assert pow(w, 16, O.P128) == 1 and pow(w, 8, O.P128) != 1
+        v = np.frombuffer(b"".join(O.f_enc(e) for e in x), np.uint8).reshape(1, n_in, 16)
+        got = vdaf.ntt(v, size)
+        assert [O.f_dec(got[0, i].tobytes()) for i in range(size)] == [sum(x[j] * pow(w, i * j, O.P128) for j in range(n_in)) % O.P128 for i in range(size)]
+        bad = v.copy()
+        bad[0, 5] = np.frombuffer(int(O.P128).to_bytes(16, "little"), np.uint8)          # p itself
+        for args, code in (((bad, 16), -3), ((v, 24), -1), ((v, 8), -1), ((v, 1 << 21), -1), ((v, 8192), -103)):
+            with pytest.raises(W.WhError) as e:
+                vdaf.ntt(*args)
+            assert e.value.code == code
+        assert vdaf.ntt(np.zeros((0, 4, 16), np.uint8), 8).shape == (0, 8, 16)
+    finally:
+        vdaf.close()

@@ -40,7 +40,7 @@ EXPORTS = [
     "wh_ctx_synchronize", "wh_client_shard_batched", "wh_client_shard_many", "wh_test_f128_op",
     "wh_test_xof_expand", "wh_ctx_set_profiling", "wh_ctx_kernel_times",
     "wh_ctx_set_test_sampler_bound", "wh_client_set_test_sampler_bound",
-    "wh_test_f64_op", "wh_flp_query_batch", "wh_flp_decide_batch", "wh_flp_encode", "wh_flp_prove", "wh_hh_bucket_accumulate_u32_dev", "wh_prio3_prepare_init_batch_dev", "wh_prio3_prepare_init_batch", "wh_prio3_prepare_finish_batch",
+    "wh_test_f64_op", "wh_ntt_f128_batch", "wh_flp_query_batch", "wh_flp_decide_batch", "wh_flp_encode", "wh_flp_prove", "wh_hh_bucket_accumulate_u32_dev", "wh_prio3_prepare_init_batch_dev", "wh_prio3_prepare_init_batch", "wh_prio3_prepare_finish_batch",
     "wh_hh_key_chain_len", "wh_hh_ctx_create", "wh_hh_eval_and_check_batch_dev", "wh_hh_eval_and_check_batch", "wh_hh_buckets",
     "wh_hh_aggregate", "wh_hh_aggregate_dev", "wh_hh_gen_key_chain", "wh_flp_prove_batch", "wh_client_shard_many_gpu", "wh_sort_by_testing_id_dev", "wh_sort_by_testing_id", "wh_keep_mask_dev",
     "wh_sort_by_testing_id_noalloc_dev", "wh_grouptest_batch_proofs_dev", "wh_grouptest_split_proofs_dev", "wh_hh_bucket_sum_f128_dev", "wh_hh_bucket_accumulate_f128_dev", "wh_hh_eval_and_sketch_batch_dev", "wh_hh_sketch_subtract_dev", "wh_ctx_lock", "wh_ctx_unlock", "wh_host_alloc", "wh_host_free", "wh_comm_unique_id", "wh_comm_init", "wh_comm_destroy", "wh_comm_rank",
@@ -85,6 +85,7 @@ lib.wh_test_f64_xof_expand.argtypes = [vp, vp, u32, u32, vp, u32, u32, u64, vp]
 lib.wh_prio3_count_set_test_sampler_bound.argtypes = [vp, u64]
 lib.wh_flp_query_batch.argtypes = [vp, vp, vp, vp, vp, u32, u64, vp, vp]
 lib.wh_flp_decide_batch.argtypes = [vp, vp, u64, vp]
+lib.wh_ntt_f128_batch.argtypes = [vp, vp, u64, u64, i32, u64, vp]
 lib.wh_flp_encode.argtypes = [C.POINTER(Params), vp, vp]
 lib.wh_flp_prove.argtypes = [C.POINTER(Params), vp, vp, vp, vp]
 lib.wh_ctx_set_test_sampler_bound.argtypes = [vp, vp]

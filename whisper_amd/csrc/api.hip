@@ -13,6 +13,7 @@
 #include "aes_host.hpp"
 #include "hh_dev.hpp"
 #include "prove_dev.hpp"
+#include "ntt_dev.hpp"
 #include "shard_dev.hpp"
 #include "sort_dev.hpp"
 #include "kernels.hip"
@@ -1410,6 +1411,34 @@ int32_t wh_test_f128_op(wh_ctx *c, int32_t op, const uint8_t *a, const uint8_t *
     hipLaunchKernelGGL(k_test_f128, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, da, db, dout, (uint32_t)n, op);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(out, dout, 16 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return WH_OK;
+}
+
+int32_t wh_ntt_f128_batch(wh_ctx *c, const uint8_t *in, uint64_t n_in, uint64_t size, int32_t inverse, uint64_t n, uint8_t *out) {
+    if (!c || !out || !size || (size & (size - 1)) || n_in > size || (n && n_in && !in)) return WH_ERR_PARAM;
+    WH_LOCK(c);
+    if (n > 0x7fffffffull) return WH_ERR_PARAM;
+    if (size > (1ull << 20)) return WH_ERR_PARAM;             // fft.rs:42-44: FftError::SizeTooLarge (MAX_ROOTS)
+    if (size > (1ull << NTT_MAX_LOG2)) { c->err = "transforms above 4096 points do not fit the kernel's LDS"; return WH_ERR_UNSUPPORTED; }
+    const uint32_t lg = log2_u32((uint32_t)size);
+    if (!n) return WH_OK;
+    // decode: every element must be a canonical residue (field.rs:405-423), as for every other entry point
+    for (uint64_t k = 0; k < n * n_in; k++) {
+        uint64_t lo, hi;
+        memcpy(&lo, in + 16 * k, 8); memcpy(&hi, in + 16 * k + 8, 8);
+        if (!f_in_range(lo, hi)) return WH_ERR_MODULUS;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    int32_t rc;
+    const uint64_t in_b = 16 * n * (n_in ? n_in : 1), out_b = 16 * n * size;
+    if ((rc = ensure(c, c->d_tmp_a, c->tmp_a_cap, in_b))) return rc;
+    if ((rc = ensure(c, c->d_tmp_c, c->tmp_c_cap, out_b))) return rc;
+    if (n_in) HIPCHK(c, hipMemcpyAsync(c->d_tmp_a, in, 16 * n * n_in, hipMemcpyHostToDevice, c->stream));
+    const int e = launch_ntt_f128(reinterpret_cast<const F128 *>(c->d_tmp_a), (uint32_t)n_in, lg, inverse != 0, root_of_unity(lg),
+                                  f_inv(f_small(size)), (uint32_t)n, reinterpret_cast<F128 *>(c->d_tmp_c), c->stream);
+    if (e) { c->err = std::string("ntt launch: ") + hipGetErrorString((hipError_t)e); return WH_ERR_HIP; }
+    HIPCHK(c, hipMemcpyAsync(out, c->d_tmp_c, out_b, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return WH_OK;
 }

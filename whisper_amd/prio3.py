@@ -242,6 +242,16 @@ class Prio3:
                                                first_client_id, n, d_leader_reports, d_helper_reports), "shard_batched_many (GPU)")
         self.n_last = 0
 
+    def ntt(self, vectors, size, inverse=False):
+        """discrete_fourier_transform (fft.rs:31-85) of every row of `vectors` (uint8 [n, n_in, 16] residues), zero-padded to
+        `size`; inverse=True adds inv_finish (fft.rs:102-115).  Returns uint8 [n, size, 16]."""
+        v = np.ascontiguousarray(vectors, dtype=np.uint8)
+        n, n_in = v.shape[0], v.shape[1]
+        out = np.zeros((n, size, 16), np.uint8)
+        self._chk(lib.wh_ntt_f128_batch(self._ctx, v.ctypes.data if v.size else None, n_in, size, 1 if inverse else 0, n, out.ctypes.data),
+                  "ntt_f128_batch")
+        return out
+
     def flp_decide(self, verifiers):
         v = np.ascontiguousarray(verifiers, dtype=np.uint8)
         n = v.shape[0]
