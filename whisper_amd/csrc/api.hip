@@ -1027,6 +1027,11 @@ static int32_t sum_rows(wh_ctx *c, const F128 *rows, const uint8_t *d_keep, uint
         // long rows (sketches): the columns alone fill the chip; a few slabs of rows on top
         const uint32_t gx = (len + 255) / 256;
         uint64_t gy = 4096 / gx; if (gy < 1) gy = 1; if (gy > n) gy = n; if (gy > 64) gy = 64;
+        if (gy == 1) {
+            hipLaunchKernelGGL(k_agg_cols_direct, dim3(gx), dim3(256), 0, c->stream, rows, d_keep, n, len, extra, d_out);
+            HIPCHK(c, hipGetLastError());
+            return WH_OK;
+        }
         const uint64_t rps = (n + gy - 1) / gy;
         gy = (n + rps - 1) / rps;
         if ((rc = ensure(c, c->d_partials, c->partials_cap, gy * len))) return rc;

@@ -1106,21 +1106,49 @@ __global__ void __launch_bounds__(256) k_agg_partial(const F128 *rows, const uin
         partials[((uint64_t)blockIdx.x * rstep + sub) * len + e] = acc;
     }
 }
-// Long rows (a Field128 sketch: 258 x 2^depth elements): thread per column, grid.y slabs of rows, one partial row per slab
+// Long rows (a Field128 sketch: 258 x 2^depth elements): thread per column.  The sum of column e over rows [r0, r1) in 192 bits;
+// eight 16-byte loads in flight per lane (keep[] is uniform over the lanes: a scalar branch), one carry chain after them.
+__device__ __forceinline__ void col_sum192(const F128 *rows, const uint8_t *keep, uint64_t r0, uint64_t r1, uint32_t len, uint32_t e,
+                                           uint64_t &lo, uint64_t &hi, uint64_t &ov) {
+    auto add = [&](const F128 &v) {
+        const u128 s = (((u128)hi << 64) | lo) + f_u(v);
+        ov += s < f_u(v);
+        lo = (uint64_t)s; hi = (uint64_t)(s >> 64);
+    };
+    uint64_t r = r0;
+    for (; r + 8 <= r1; r += 8) {
+        F128 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            v[u] = f_zero();
+            if (!keep || keep[r + u]) v[u] = rows[(r + u) * len + e];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) add(v[u]);
+    }
+    for (; r < r1; r++)
+        if (!keep || keep[r]) add(rows[r * len + e]);
+}
+// grid.y slabs of rows, one partial row per slab
 __global__ void __launch_bounds__(256) k_agg_partial_cols(const F128 *rows, const uint8_t *keep, uint64_t n, uint32_t len,
                                                           uint32_t rows_per_slab, F128 *partials) {
     const uint32_t e = blockIdx.x * 256 + threadIdx.x;
     if (e >= len) return;
     const uint64_t r0 = (uint64_t)blockIdx.y * rows_per_slab, r1 = r0 + rows_per_slab < n ? r0 + rows_per_slab : n;
     uint64_t lo = 0, hi = 0, ov = 0;
-    for (uint64_t r = r0; r < r1; r++) {
-        if (keep && !keep[r]) continue;
-        const F128 v = rows[r * len + e];
-        u128 s = (((u128)hi << 64) | lo) + f_u(v);
-        ov += s < f_u(v);
-        lo = (uint64_t)s; hi = (uint64_t)(s >> 64);
-    }
+    col_sum192(rows, keep, r0, r1, len, e, lo, hi, ov);
     partials[(uint64_t)blockIdx.y * len + e] = f_reduce256(lo, hi, ov, 0);
+}
+// one slab (the columns alone fill the chip): the sum goes straight to `out`, on top of `extra` (may be NULL, may be `out`:
+// every lane reads its own element before it writes it) -- no partial rows, no second pass
+__global__ void __launch_bounds__(256) k_agg_cols_direct(const F128 *rows, const uint8_t *keep, uint64_t n, uint32_t len,
+                                                         const F128 *extra, F128 *out) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= len) return;
+    uint64_t lo = 0, hi = 0, ov = 0;
+    if (extra) { const F128 x = extra[e]; lo = x.lo; hi = x.hi; }      // any 128-bit value: the reduction below makes it canonical
+    col_sum192(rows, keep, 0, n, len, e, lo, hi, ov);
+    out[e] = f_reduce256(lo, hi, ov, 0);
 }
 // second pass over the partial sums: 16 columns per workgroup, 16 lanes down each column; `extra` (may be NULL, may be
 // `out`) is one more row: the running sum of an accumulating caller
