@@ -133,6 +133,44 @@ def test_prepare_init_matches_oracle(name, cfg, na, n):
         vdaf.close()
 
 
+@pytest.mark.parametrize("cfg,na", [((W.SUMVEC, 16, 16, 8), 2), ((W.SUMVEC, 8, 40, 5), 3), ((W.HISTOGRAM, 0, 128, 64), 2)],
+                         ids=["sumvec_2", "sumvec_ragged_3", "histogram_2"])
+def test_prepare_init_sampler_rejection_branch(cfg, na):
+    """The un-batched path shares k_meas with the batched one: a Helper whose share stream has a rejected chunk leaves the lane-pair
+    hand-over and is redone by the general path.  With the test bound at ~p/3 (two of three chunks skipped, prng.rs:73-99) every
+    Helper key takes that route; prepare shares and out shares still equal the oracle's, which samples with the same bound."""
+    circ, bits, ln, ch = cfg
+    p = W.Prio3Params(circ, bits, ln, ch, na)
+    op = O.params(circ, bits, ln, ch, na)
+    vk = bytes(det(b"vk-rej", 16))
+    bound = O.P128 // 3 + 999
+    n = 7
+    vdaf = W.Prio3(p)
+    try:
+        O.set_test_sampler_bound(bound)
+        vdaf.set_test_sampler_bound(bound)
+        shards = []
+        for i in range(n):
+            nonce = bytes(det(b"rn%d" % i, 16))
+            rand = bytes(det(b"rr%d" % i, O.prio3_rand_size(op)))
+            shards.append((nonce,) + tuple(O.prio3_shard(op, measurement_for(circ, bits, ln, i), nonce, rand)))
+        all_prep = []
+        for agg_id in range(na):
+            keys = [W.Prio3.encode_vdaf_key(agg_id, ps, ish[agg_id], nonce) for nonce, ps, ish in shards]
+            prep, status = vdaf.prepare_init_encoded_keys(vk, keys)
+            outs = vdaf.out_shares()
+            assert not status.any()
+            for j, (nonce, ps, ish) in enumerate(shards):
+                rc, want_prep, want_out = O.prio3_prepare_init(op, vk, agg_id, nonce, ps, ish[agg_id])
+                assert rc == 0 and prep[j].tobytes() == want_prep and outs[j].tobytes() == want_out
+            all_prep.append(prep)
+        _, status = vdaf.prepare_finish(all_prep)
+        assert not status.any()
+    finally:
+        O.set_test_sampler_bound(None)
+        vdaf.close()
+
+
 @pytest.mark.parametrize("cfg,na", [((W.SUMVEC, 8, 10, 9), 2), ((W.HISTOGRAM, 0, 11, 3), 3), ((W.AVERAGE, 16, 0, 0), 2)],
                          ids=["sumvec_2", "histogram_3", "sum_2"])
 def test_prepare_init_mutated_keys_differential_fuzz(cfg, na):

@@ -517,10 +517,27 @@ int32_t wh_prio3_prepare_init_batch_dev(wh_ctx *c, const uint8_t verify_key[16],
     { KTimer t_(c, WH_K_PARSE);
     hipLaunchKernelGGL(k_parse_base, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, d_blob, d_offsets, nb, d_status,
                        d_prep, d_out); }
-    { KTimer t_(c, WH_K_EXPAND);
-    launch_expand(c->P, c->W, npad, 0, c->stream); }
+    // as in the batched path: the Helpers' proof shares on the side stream, the measurement shares and their joint-rand
+    // sponges in k_meas (Leader lanes absorb from the key, Helper lane pairs squeeze and absorb in step); keys whose share
+    // stream had a rejected chunk go through the general path.  WH_BASE_NO_MEAS keeps the two-pass form (expand, then absorb).
+    const bool paired = !getenv("WH_BASE_NO_MEAS");
+    if (paired) {
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        { KTimer t_(c, WH_K_EXPAND, c->stream2);
+        launch_expand(c->P, c->W, npad, 1, c->stream2); }
+        HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
+        { KTimer t_(c, WH_K_MEAS);
+        launch_meas(c->P, c->W, 0, npad, d_status, c->stream); }
+        launch_expand(c->P, c->W, npad, 2, c->stream);
+        launch_meas(c->P, c->W, 1, npad, d_status, c->stream);
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    } else {
+        KTimer t_(c, WH_K_EXPAND);
+        launch_expand(c->P, c->W, npad, 0, c->stream);
+    }
     { KTimer t_(c, WH_K_HASH);
-    hipLaunchKernelGGL(k_hash_base, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, vk0, vk1, d_status); }
+    hipLaunchKernelGGL(k_hash_base, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, vk0, vk1, d_status, paired ? 1u : 0u); }
     { KTimer t_(c, WH_K_QUERY);
     hipLaunchKernelGGL(q.fn, dim3(q.polyeval ? (nb + 3) / 4 : nb), dim3(64 * q.waves), q.lds, c->stream, c->P, c->W, d_prep,
                        d_out, d_status); }

@@ -378,7 +378,8 @@ __global__ void k_parse_base(Prio3Dev P, Workspace W, const uint8_t *blob, const
 // the public share's parts with the own part substituted (:482-493); joint randomness XOF(seed, 3).
 // The joint randomness goes where the batched path keeps run 2's, so the query kernels read it
 // the same way; the seed is kept for prepare_next's check (:2407-2424).
-__global__ void __launch_bounds__(256) k_hash_base(Prio3Dev P, Workspace W, uint64_t vk0, uint64_t vk1, int32_t *status) {
+// first_stage 1: the own joint-rand part is already in sc->own (k_meas computed it beside the Helper's share expansion).
+__global__ void __launch_bounds__(256) k_hash_base(Prio3Dev P, Workspace W, uint64_t vk0, uint64_t vk1, int32_t *status, uint32_t first_stage) {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t i;
     if (!report_of_slot(W, slot, i) || status[i] != ST_OK) return;
@@ -389,7 +390,7 @@ __global__ void __launch_bounds__(256) k_hash_base(Prio3Dev P, Workspace W, uint
     SpongeG s;
     F128 sd = f_zero();
 #pragma unroll 1
-    for (uint32_t stg = 0; stg < 4; stg++) {
+    for (uint32_t stg = first_stage; stg < 4; stg++) {
         uint32_t usage = 0, l1 = 0, l2 = 0, l3 = 0, emit_n = 0;
         uint64_t k0 = 0, k1 = 0;
         const uint8_t *p1 = nullptr, *p2 = nullptr, *p3 = nullptr;
