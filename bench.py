@@ -39,6 +39,9 @@ WORKLOADS = {
     # BASELINE.json configs[1]
     "histogram": dict(circuit=W.HISTOGRAM, bits=0, length=128, chunk=64, reports_per_gpu=100_000,
                       desc="Prio3 Histogram length=128 chunk_size=64, 100k clients"),
+    # the servers' third aggregation function (agg_fn = average, AVG_BITS = 64, bin-utils/src/lib.rs:34): PolyEval circuit
+    "average": dict(circuit=W.AVERAGE, bits=64, length=0, chunk=0, reports_per_gpu=500_000,
+                    desc="Prio3 Average bits=64 (AVG_BITS), 500k clients"),
 }
 # heavy hitters (server-hh): (repetitions, buckets) from the recovery threshold, bin-utils/src/lib.rs:66-88; one step =
 # expansion (eval_and_check) of clients x repetitions key chains + masked sketch sums
@@ -135,8 +138,10 @@ def main():
         rng = np.random.default_rng(1000 + rank)
         if wl["circuit"] == W.SUMVEC:
             meas = rng.integers(0, 1 << wl["bits"], (n, wl["length"]), dtype=np.uint64)
-        else:
+        elif wl["circuit"] == W.HISTOGRAM:
             meas = rng.integers(0, wl["length"], (n, 1), dtype=np.uint64)
+        else:
+            meas = rng.integers(0, 1 << 16, (n, 1), dtype=np.uint64)       # rng.gen::<u16>() as u128, client-batch-prio3 main.rs:101
         nonces = rng.integers(0, 256, (n, 16), dtype=np.uint8)
         rands = rng.integers(0, 256, (n, 144), dtype=np.uint8)
         L, H = s.leader_report_len, s.helper_report_len
@@ -324,8 +329,7 @@ def main():
     if rank == 0:
         value = world * n * args.steps / elapsed
         result = {
-            "metric": "verified+aggregated client reports/sec (node), Prio3 SumVec" if wl["circuit"] == W.SUMVEC else
-                      "verified+aggregated client reports/sec (node), Prio3 Histogram",
+            "metric": "verified+aggregated client reports/sec (node), Prio3 " + {W.SUMVEC: "SumVec", W.HISTOGRAM: "Histogram", W.AVERAGE: "Average"}[wl["circuit"]],
             "value": value, "unit": "reports/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u128 (Field128 mod p) + u64 (Keccak lanes)", "data": "synthetic",

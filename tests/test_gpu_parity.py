@@ -471,3 +471,35 @@ def test_mutated_reports_differential_fuzz(cfg):
             assert np.array_equal(vdaf.aggregate(None), O.prio3_aggregate(o_outs, p.output_len, ok.astype(np.uint8)))
     finally:
         vdaf.close()
+
+
+@pytest.mark.parametrize("length", [1, 3, 100, 255, 256, 300, 5000])
+def test_masked_row_sums_every_row_shape(length):
+    """wh_f128_sum_rows_dev (the aggregation kernels behind wh_prio3_aggregate*, the multi-GPU combine and the Field128 sketch sums)
+    against Python integers for the three launch shapes -- short rows swept side by side (Average's output_len = 1), rows of at
+    least 256 elements, long rows by columns -- with a keep mask, non-canonical and all-ones inputs, and row counts around the
+    slab sizes."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(1000 + length)
+    vdaf = W.Prio3(W.Prio3Params(W.SUMVEC, 2, 5, 3))
+    try:
+        for n in (1, 2, 257, 4099):
+            rows = rng.integers(0, 1 << 32, (n, length, 4), dtype=np.uint64).astype(np.uint32)
+            rows[:, :, 3] >>= 1                                  # below p ...
+            rows[0, 0, :] = 0xffffffff                           # ... except an all-ones element (reduced mod p, as documented)
+            keep = (rng.integers(0, 4, n) != 0).astype(np.uint8)
+            keep[0] = 1
+            d_rows = torch.from_numpy(rows.view(np.int32).copy()).to(dev)
+            d_keep = torch.from_numpy(keep).to(dev)
+            d_out = torch.zeros(length * 4, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            vdaf.sum_rows_dev(d_rows.data_ptr(), n, length, d_keep.data_ptr(), d_out.data_ptr())
+            vdaf.synchronize()
+            got = d_out.cpu().numpy().view(np.uint32).reshape(length, 4).astype(object)
+            vals = rows.astype(object)
+            ints = vals[:, :, 0] + (vals[:, :, 1] << 32) + (vals[:, :, 2] << 64) + (vals[:, :, 3] << 96)
+            want = [int(sum(ints[r, e] for r in range(n) if keep[r]) % O.P128) for e in range(length)]
+            assert [int(g[0]) | int(g[1]) << 32 | int(g[2]) << 64 | int(g[3]) << 96 for g in got] == want
+    finally:
+        vdaf.close()

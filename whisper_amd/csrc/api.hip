@@ -1062,9 +1062,9 @@ static int32_t sum_rows(wh_ctx *c, const F128 *rows, const uint8_t *d_keep, uint
     uint64_t rpb = (n + 2047) / 2048;
     if (rpb < rstep) rpb = rstep;
     const uint32_t nblocks = (uint32_t)((n + rpb - 1) / rpb);
-    if ((rc = ensure(c, c->d_partials, c->partials_cap, (uint64_t)nblocks * rstep * len))) return rc;
+    if ((rc = ensure(c, c->d_partials, c->partials_cap, (uint64_t)nblocks * len))) return rc;
     hipLaunchKernelGGL(k_agg_partial, dim3(nblocks), dim3(256), 0, c->stream, rows, d_keep, n, len, (uint32_t)rpb, c->d_partials);
-    hipLaunchKernelGGL(k_agg_final, dim3((len + 15) / 16), dim3(256), 0, c->stream, c->d_partials, nblocks * rstep, len, extra, d_out);
+    hipLaunchKernelGGL(k_agg_final, dim3((len + 15) / 16), dim3(256), 0, c->stream, c->d_partials, nblocks, len, extra, d_out);
     HIPCHK(c, hipGetLastError());
     return WH_OK;
 }

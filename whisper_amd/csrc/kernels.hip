@@ -1092,19 +1092,31 @@ __global__ void __launch_bounds__(256) k_agg_partial(const F128 *rows, const uin
     const uint32_t tpr = len < blockDim.x ? len : blockDim.x;  // threads across one row
     const uint32_t rstep = blockDim.x / tpr;                   // rows per sweep
     const uint32_t sub = threadIdx.x / tpr, col0 = threadIdx.x % tpr;
-    if (sub >= rstep) return;
-    for (uint32_t e = col0; e < len; e += tpr) {
-        uint64_t lo = 0, hi = 0, ov = 0;
-        for (uint64_t r = r0 + sub; r < r1; r += rstep) {
-            if (keep && !keep[r]) continue;
-            F128 v = rows[r * len + e];
-            u128 s = (((u128)hi << 64) | lo) + f_u(v);
-            ov += s < f_u(v);
-            lo = (uint64_t)s; hi = (uint64_t)(s >> 64);
+    __shared__ F128 red[256];
+    F128 mine = f_zero();
+    if (sub < rstep)
+        for (uint32_t e = col0; e < len; e += tpr) {
+            uint64_t lo = 0, hi = 0, ov = 0;
+            for (uint64_t r = r0 + sub; r < r1; r += rstep) {
+                if (keep && !keep[r]) continue;
+                F128 v = rows[r * len + e];
+                u128 s = (((u128)hi << 64) | lo) + f_u(v);
+                ov += s < f_u(v);
+                lo = (uint64_t)s; hi = (uint64_t)(s >> 64);
+            }
+            // fold the overflow count: ov * 2^128
+            mine = f_reduce256(lo, hi, ov, 0);
+            if (rstep == 1) partials[(uint64_t)blockIdx.x * len + e] = mine;
         }
-        // fold the overflow count: ov * 2^128
-        F128 acc = f_reduce256(lo, hi, ov, 0);
-        partials[((uint64_t)blockIdx.x * rstep + sub) * len + e] = acc;
+    if (rstep == 1) return;                     // uniform over the launch
+    // short rows (len < 256): rstep rows were swept side by side; one partial row per workgroup all the same, so that the
+    // second pass reads as many rows as there are workgroups, not rstep times as many (Average: len = 1, rstep = 256)
+    red[threadIdx.x] = mine;
+    __syncthreads();
+    if (sub == 0) {
+        F128 acc = mine;
+        for (uint32_t k = 1; k < rstep; k++) acc = f_add(acc, red[k * tpr + col0]);
+        partials[(uint64_t)blockIdx.x * len + col0] = acc;
     }
 }
 // Long rows (a Field128 sketch: 258 x 2^depth elements): thread per column.  The sum of column e over rows [r0, r1) in 192 bits;
