@@ -38,8 +38,8 @@ struct wh_ctx {
     hipStream_t stream = nullptr;
     // side stream for the short kernels that do not depend on the measurement sponges (proof-share
     // expansion, public-parts hash / RLC / testing id): they slip in beside k_meas
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t stream2 = nullptr, stream3 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
     // host-buffer entry points: copy stream, "chunk b has arrived" / "chunk b has been verified" events, pinned staging
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
@@ -310,6 +310,8 @@ int32_t wh_ctx_create(int32_t device_id, const wh_prio3_params *params, wh_ctx *
     if (hipSetDevice(device_id) != hipSuccess) return fail(WH_ERR_HIP);
     if (hipStreamCreate(&c->stream) != hipSuccess) return fail(WH_ERR_HIP);
     if (hipStreamCreate(&c->stream2) != hipSuccess) return fail(WH_ERR_HIP);
+    if (hipStreamCreate(&c->stream3) != hipSuccess) return fail(WH_ERR_HIP);
+    if (hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming) != hipSuccess) return fail(WH_ERR_HIP);
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(WH_ERR_HIP);
     if (hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) return fail(WH_ERR_HIP);
     if (hipEventCreateWithFlags(&c->ev_bad, hipEventDisableTiming) != hipSuccess) return fail(WH_ERR_HIP);
@@ -358,6 +360,7 @@ void wh_ctx_destroy(wh_ctx *c) {
     wh::count64_free(c->count); c->count = nullptr;
     wh::grouptest_free(c->grouptest); c->grouptest = nullptr;
     if (c->stream2) hipStreamSynchronize(c->stream2);
+    if (c->stream3) hipStreamSynchronize(c->stream3);
     void *ptrs[] = {c->d_omega, c->d_stab, c->d_aes, c->d_out_shares, c->d_status_own, c->d_status_keep, c->d_tmp_a, c->d_tmp_b, c->d_tmp_c, c->d_keep_eff, c->d_partials,
                     c->d_blob, c->d_offsets, c->d_tags, c->d_ids, c->d_prep, c->W.desc, c->W.scal, c->W.weights, c->W.wlimbs, c->W.pows, c->W.rlc,
                     c->W.hrows, c->W.hlist, c->W.llist, c->W.dirty, c->W.counters,
@@ -374,6 +377,8 @@ void wh_ctx_destroy(wh_ctx *c) {
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->ev_bad) hipEventDestroy(c->ev_bad);
     if (c->stream2) hipStreamDestroy(c->stream2);
+    if (c->ev_join3) hipEventDestroy(c->ev_join3);
+    if (c->stream3) hipStreamDestroy(c->stream3);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -451,9 +456,16 @@ static int32_t prepare_range(wh_ctx *c, const PrepPlan &pl, const uint8_t *d_blo
         }
         { KTimer t_(c, WH_K_EXPAND, s2);
         launch_expand(c->P, c->W, npad, 1, s2); }
+        // Very short measurement shares (Histogram of 128, Average): the step is a chain of kernel latencies, and job B gets a
+        // stream of its own beside the proof-share expansion (Histogram 3.12 -> 2.92 ms per 100 k reports, Average unchanged).
+        // From cfg-1's 2 048 elements on it stays behind the expansion: beside it, it takes wave slots before k_meas has placed
+        // its wavefronts (cfg-1: k_meas 16.0 -> 18.3 ms, step 29.5 -> 30.1 ms; sumvec_large loses 0.4-1.5 ms).
+        const bool b_third = hash_b_side && c->z.input_len <= 256 && !getenv("WH_NO_THIRD_STREAM");
+        if (b_third) HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
         if (hash_b_side)
-            hipLaunchKernelGGL(k_hash, dim3(npad / 256), dim3(256), 0, s2, c->P, c->W, npad, 1u, pl.vk0, pl.vk1, c->d_aes,
-                               d_ids + 16 * base, d_status + base);
+            hipLaunchKernelGGL(k_hash, dim3(npad / 256), dim3(256), 0, b_third ? c->stream3 : s2, c->P, c->W, npad, 1u, pl.vk0, pl.vk1,
+                               c->d_aes, d_ids + 16 * base, d_status + base);
+        if (b_third) HIPCHK(c, hipEventRecord(c->ev_join3, c->stream3));
         if (side) HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
         { KTimer t_(c, WH_K_MEAS);
         launch_meas(c->P, c->W, 0, npad, d_status + base, c->stream); }     // measurement shares and their sponges
@@ -461,6 +473,7 @@ static int32_t prepare_range(wh_ctx *c, const PrepPlan &pl, const uint8_t *d_blo
         launch_expand(c->P, c->W, npad, 2, c->stream);
         launch_meas(c->P, c->W, 1, npad, d_status + base, c->stream);
         if (side) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        if (b_third) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join3, 0));
         { KTimer t_(c, WH_K_HASH);
         hipLaunchKernelGGL(k_hash, dim3((hash_b_side ? 1 : 2) * npad / 256), dim3(256), 0, c->stream, c->P, c->W, npad,
                            hash_b_side ? 0u : 2u, pl.vk0, pl.vk1, c->d_aes, d_ids + 16 * base, d_status + base); }
