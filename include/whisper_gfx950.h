@@ -233,6 +233,9 @@ int32_t wh_comm_unique_id(uint8_t id[WH_COMM_ID_BYTES]);
 int32_t wh_comm_init(wh_ctx *ctx, const uint8_t *id, int32_t rank, int32_t world);
 int32_t wh_comm_destroy(wh_ctx *ctx);
 int32_t wh_comm_rank(wh_ctx *ctx, int32_t *rank, int32_t *world);
+/* why RCCL could not be bound (the loader's message), "" if it could or if no call has tried yet; the library named by
+ * WH_RCCL_LIBRARY (read at the first attempt) is tried instead of the default names when it is set */
+const char *wh_comm_why(void);
 /* d_partial[output_len] (this GPU's aggregate share, device) -> d_agg[output_len] = sum over ranks mod p, on every rank;
  * asynchronous on the context stream.  The _f128_ form takes the row length (any Field128 row). */
 int32_t wh_prio3_allgather_reduce_dev(wh_ctx *ctx, const uint8_t *d_partial, uint8_t *d_agg);
@@ -359,6 +362,29 @@ int32_t wh_grouptest_split_proofs_dev(wh_ctx *ctx, const uint8_t *d_ids, const u
 
 int32_t wh_ctx_synchronize(wh_ctx *ctx);
 
+/* ---- tuning and test knobs ---- */
+/* No counterpart in the reference.  Every knob lives in the context; the environment variable named beside it is read ONCE,
+ * by wh_ctx_create, as the knob's initial value, and never again: no entry point's behaviour depends on the environment of
+ * the moment it is called.  Results never depend on a knob, only the launch shapes do. */
+enum {
+    WH_OPT_MAX_SUBBATCH = 0,        /* WH_MAX_SUBBATCH: reports per verification sub-batch (>= 64; 0 = the library's choice) */
+    WH_OPT_HOST_CHUNK_MB = 1,       /* WH_HOST_CHUNK_MB: MiB per H2D chunk of wh_prio3_prepare_batch (default 2048) */
+    WH_OPT_HOST_COPY_THREADS = 2,   /* WH_HOST_COPY_THREADS: host threads staging pageable input (0 = all cores, at most 8) */
+    WH_OPT_HH_SUBBATCH = 3,         /* WH_HH_SUBBATCH: key chains per heavy-hitter sub-batch (0 = the library's choice) */
+    WH_OPT_HH_SUM_LDS = 4,          /* WH_HH_SUM_LDS: bytes of LDS a side-stream sketch-sum workgroup reserves (default 120 KiB) */
+    WH_OPT_SIDE_STREAM = 5,         /* 0 if WH_NO_SIDE_STREAM is set: proof-share expansion on the main stream (long-share path) */
+    WH_OPT_HASH_B_SIDE = 6,         /* 0 if WH_HASH_B_MAIN is set: public-parts hash / RLC / testing ids in the main hash launch */
+    WH_OPT_THIRD_STREAM = 7,        /* 0 if WH_NO_THIRD_STREAM is set */
+    WH_OPT_BASE_PAIRED = 8,         /* 0 if WH_BASE_NO_MEAS is set: prepare_init expands, then absorbs, in two passes */
+    WH_OPT_CHAIN_MAX_INPUT_LEN = 9, /* WH_CHAIN_MAX_INPUT_LEN: circuits with input_len up to this run all their sponges in one
+                                     * launch (chain.hip) instead of the k_meas pipeline */
+    WH_OPT_CHAIN_PREFETCH = 10,     /* WH_CHAIN_PREFETCH: 1 = that launch keeps the next rate block's loads in flight (3 waves/SIMD) */
+    WH_NUM_OPTS = 11
+};
+#define WH_CHAIN_MAX_INPUT_LEN_DEFAULT 2048u
+int32_t wh_ctx_set_option(wh_ctx *ctx, int32_t option, uint64_t value);
+int32_t wh_ctx_get_option(wh_ctx *ctx, int32_t option, uint64_t *value);
+
 /* ---- measurement ---- */
 /* no counterpart in the reference (it prints wall-clock timers, server-batch-prio3/src/main.rs:
  * 276,340-341,414-421).  With profiling on, every kernel launch is bracketed by HIP events on
@@ -366,7 +392,7 @@ int32_t wh_ctx_synchronize(wh_ctx *ctx);
  * launch counts per kernel (indices WH_K_*), optionally resetting them. */
 enum { WH_K_PARSE = 0, WH_K_EXPAND = 1, WH_K_HASH = 2, WH_K_QUERY = 3, WH_K_AGG = 4, WH_K_HH = 5, WH_K_MEAS = 6,
        WH_K_HH_MAIN = 7, WH_K_HH_SUPPORT = 8, WH_K_HH_CHAIN = 9, WH_K_HH_FINAL = 10, WH_K_PROVE = 11, WH_K_SORT = 12,
-       WH_NUM_KERNELS = 13 };
+       WH_K_CHAIN = 13, WH_NUM_KERNELS = 14 };
 int32_t wh_ctx_set_profiling(wh_ctx *ctx, int32_t on);
 int32_t wh_ctx_kernel_times(wh_ctx *ctx, double *ms, uint64_t *launches, int32_t reset);
 

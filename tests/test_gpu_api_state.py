@@ -228,7 +228,6 @@ def test_host_buffer_path_in_chunks_pageable_and_pinned(monkeypatch):
     keep[::7] = 0
     vdaf = W.Prio3(p)
     try:
-        monkeypatch.delenv("WH_HOST_CHUNK_MB", raising=False)
         ref = vdaf.prepare_batch_host(VK, blob, off)
         ref_agg = vdaf.aggregate(keep)
         assert ref[2][17] == WH_ERR_SHORT and ref[2][150] == -4 and ref[2][299] == WH_ERR_SHORT
@@ -237,7 +236,7 @@ def test_host_buffer_path_in_chunks_pageable_and_pinned(monkeypatch):
         sblob, soff = blob_of([alice[i] for i in sample])
         o_tags, o_ids, o_status, _ = O.prio3_prepare_batch(O.params(*cfg), VK, sblob, soff, nthreads=4)
         assert np.array_equal(ref[0][sample], o_tags) and np.array_equal(ref[1][sample], o_ids) and np.array_equal(ref[2][sample], o_status)
-        monkeypatch.setenv("WH_HOST_CHUNK_MB", "1")
+        vdaf.set_option("host_chunk_mb", 1)
         got = vdaf.prepare_batch_host(VK, blob, off)
         assert all(np.array_equal(a, b) for a, b in zip(got, ref))
         assert np.array_equal(vdaf.aggregate(keep), ref_agg)
@@ -250,7 +249,7 @@ def test_host_buffer_path_in_chunks_pageable_and_pinned(monkeypatch):
             got = vdaf.prepare_batch_host(VK, pinned, off)
             assert all(np.array_equal(a, b) for a, b in zip(got, ref))
             assert np.array_equal(vdaf.aggregate(keep), ref_agg)
-            monkeypatch.setenv("WH_HOST_COPY_THREADS", "1")
+            vdaf.set_option("host_copy_threads", 1)
             got = vdaf.prepare_batch_host(VK, blob, off)       # pageable again, one copy thread
             assert all(np.array_equal(a, b) for a, b in zip(got, ref))
         finally:

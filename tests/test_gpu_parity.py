@@ -337,9 +337,8 @@ def test_device_pointer_path_and_large_batch_properties():
     finally:
         vdaf.close()
     # the same batch in four sub-batches (workspace reused, side stream forked and joined per sub-batch)
-    import os
-    os.environ["WH_MAX_SUBBATCH"] = "700"
     vdaf = W.Prio3(p)
+    vdaf.set_option("max_subbatch", 700)
     try:
         d_tags2 = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
         d_status.fill_(-99)
@@ -350,7 +349,6 @@ def test_device_pointer_path_and_large_batch_properties():
         assert np.array_equal(d_tags2.cpu().numpy().reshape(n, 16), tags)
         assert d_agg.cpu().numpy().tobytes() == want
     finally:
-        del os.environ["WH_MAX_SUBBATCH"]
         vdaf.close()
 
 

@@ -47,6 +47,7 @@ EXPORTS = [
     "wh_prio3_allgather_reduce_dev", "wh_f128_allgather_reduce_dev", "wh_prio3_allgather_reduce", "wh_hh_allreduce_u32_dev",
     "wh_prio3_count_prepare_init_batch", "wh_prio3_count_prepare_finish_batch", "wh_prio3_count_out_shares", "wh_prio3_count_aggregate",
     "wh_test_f64_xof_expand", "wh_prio3_count_set_test_sampler_bound",
+    "wh_ctx_set_option", "wh_ctx_get_option", "wh_comm_why",
 ]
 
 vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32
@@ -123,8 +124,16 @@ lib.wh_hh_buckets.argtypes = [vp, vp]
 lib.wh_hh_aggregate.argtypes = [vp, vp, vp]
 lib.wh_hh_aggregate_dev.argtypes = [vp, vp, vp, i32]
 lib.wh_hh_gen_key_chain.argtypes = [u32, vp, u32, vp, vp, vp, vp]
+lib.wh_ctx_set_option.argtypes = [vp, i32, u64]
+lib.wh_ctx_get_option.argtypes = [vp, i32, C.POINTER(u64)]
+lib.wh_comm_why.argtypes = []
 for _n in EXPORTS:
     getattr(lib, _n)  # AttributeError here = the library does not export what the header declares
-    if _n not in ("wh_ctx_destroy", "wh_last_error", "wh_ctx_stream", "wh_client_set_test_sampler_bound"):
+    if _n not in ("wh_ctx_destroy", "wh_last_error", "wh_ctx_stream", "wh_client_set_test_sampler_bound", "wh_comm_why"):
         getattr(lib, _n).restype = i32
 lib.wh_hh_key_chain_len.restype = u64
+lib.wh_comm_why.restype = C.c_char_p
+
+# WH_OPT_* of wh_ctx_set_option (include/whisper_gfx950.h)
+OPTIONS = {"max_subbatch": 0, "host_chunk_mb": 1, "host_copy_threads": 2, "hh_subbatch": 3, "hh_sum_lds": 4, "side_stream": 5,
+           "hash_b_side": 6, "third_stream": 7, "base_paired": 8, "chain_max_input_len": 9, "chain_prefetch": 10}

@@ -31,6 +31,39 @@ static __device__ __align__(256) uint32_t scratch[SORT_NOALLOC_MAX_N + SORT_NOAL
 namespace wh {
 void launch_expand(const Prio3Dev &P, const Workspace &W, uint32_t npad, uint32_t sel, hipStream_t stream);
 void launch_meas(const Prio3Dev &P, const Workspace &W, uint32_t mode, uint32_t npad, int32_t *status, hipStream_t stream);
+void launch_chain(const Prio3Dev &P, const Workspace &W, uint32_t npad, bool prefetch, uint64_t vk0, uint64_t vk1,
+                  const uint8_t *aes_rk, uint8_t *testing_ids, int32_t *status, hipStream_t stream);
+}
+
+// Tuning and test knobs of a context (wh_ctx_set_option).  The environment variables of the same purpose are read ONCE, in
+// wh_ctx_create, as the initial values: no entry point looks at the environment afterwards.
+struct Knobs {
+    uint64_t v[WH_NUM_OPTS] = {0};
+};
+static void knobs_from_env(Knobs &k) {
+    k.v[WH_OPT_MAX_SUBBATCH] = 0;                 // 0: the library's choice (pick_cap)
+    k.v[WH_OPT_HOST_CHUNK_MB] = 2048;
+    k.v[WH_OPT_HOST_COPY_THREADS] = 0;            // 0: hardware concurrency, at most 8
+    k.v[WH_OPT_HH_SUBBATCH] = 0;
+    k.v[WH_OPT_HH_SUM_LDS] = 120u << 10;
+    k.v[WH_OPT_SIDE_STREAM] = 1;
+    k.v[WH_OPT_HASH_B_SIDE] = 1;
+    k.v[WH_OPT_THIRD_STREAM] = 1;
+    k.v[WH_OPT_BASE_PAIRED] = 1;
+    k.v[WH_OPT_CHAIN_MAX_INPUT_LEN] = WH_CHAIN_MAX_INPUT_LEN_DEFAULT;
+    k.v[WH_OPT_CHAIN_PREFETCH] = 0;
+    auto num = [](const char *name, uint64_t &out) { if (const char *e = getenv(name)) out = strtoull(e, nullptr, 10); };
+    num("WH_MAX_SUBBATCH", k.v[WH_OPT_MAX_SUBBATCH]);
+    num("WH_HOST_CHUNK_MB", k.v[WH_OPT_HOST_CHUNK_MB]);
+    num("WH_HOST_COPY_THREADS", k.v[WH_OPT_HOST_COPY_THREADS]);
+    num("WH_HH_SUBBATCH", k.v[WH_OPT_HH_SUBBATCH]);
+    num("WH_HH_SUM_LDS", k.v[WH_OPT_HH_SUM_LDS]);
+    num("WH_CHAIN_MAX_INPUT_LEN", k.v[WH_OPT_CHAIN_MAX_INPUT_LEN]);
+    num("WH_CHAIN_PREFETCH", k.v[WH_OPT_CHAIN_PREFETCH]);
+    if (getenv("WH_NO_SIDE_STREAM")) k.v[WH_OPT_SIDE_STREAM] = 0;
+    if (getenv("WH_HASH_B_MAIN")) k.v[WH_OPT_HASH_B_SIDE] = 0;
+    if (getenv("WH_NO_THIRD_STREAM")) k.v[WH_OPT_THIRD_STREAM] = 0;
+    if (getenv("WH_BASE_NO_MEAS")) k.v[WH_OPT_BASE_PAIRED] = 0;
 }
 
 struct wh_ctx {
@@ -104,6 +137,7 @@ struct wh_ctx {
     void *comm = nullptr;        // multi-GPU state (comm.hip)
     void *count = nullptr;       // Prio3Count / Field64 state (count64.hip)
     void *grouptest = nullptr;   // job and result staging of the batch-proof kernel (grouptest.hip)
+    Knobs knobs;
     double k_ms[WH_NUM_KERNELS] = {0};
     uint64_t k_launches[WH_NUM_KERNELS] = {0};
     std::string err;
@@ -215,10 +249,8 @@ int32_t alloc_workspace(wh_ctx *c, uint64_t cap) {
     HIPCHK(c, hipMalloc((void **)&W.scal, cap * sizeof(RepScal)));
     HIPCHK(c, hipMalloc((void **)&W.weights, cap * (uint64_t)(z.calls + 1) * sizeof(F128)));
     HIPCHK(c, hipMalloc((void **)&W.rlc, cap * (uint64_t)(z.verifier_len + 5) * sizeof(F128)));
-    if (c->params.circuit != WH_AVERAGE) {
-        HIPCHK(c, hipMalloc((void **)&W.wlimbs, cap * (uint64_t)z.calls * 48));
-        HIPCHK(c, hipMalloc((void **)&W.pows, cap * sizeof(RepPow)));
-    }
+    if (c->params.circuit != WH_AVERAGE) HIPCHK(c, hipMalloc((void **)&W.wlimbs, cap * (uint64_t)z.calls * 48));
+    HIPCHK(c, hipMalloc((void **)&W.pows, cap * sizeof(RepPow)));
     HIPCHK(c, hipMalloc((void **)&W.hrows, cap * W.hrow_bytes));
     HIPCHK(c, hipMalloc((void **)&W.hlist, cap * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc((void **)&W.llist, cap * sizeof(uint32_t)));
@@ -234,8 +266,7 @@ uint64_t pick_cap(const wh_ctx *c, uint64_t n) {
     uint64_t by_mem = (64ull << 30) / (hrow + 4096);   // <= 64 GiB of expansion rows (288 GB HBM)
     uint64_t cap = 1ull << 19;
     if (cap > by_mem) cap = by_mem;
-    if (const char *e = getenv("WH_MAX_SUBBATCH")) {      // tuning / test knob: reports per sub-batch
-        const uint64_t v = strtoull(e, nullptr, 10);
+    if (const uint64_t v = c->knobs.v[WH_OPT_MAX_SUBBATCH]) {      // tuning / test knob: reports per sub-batch
         if (v >= 64 && v < cap) cap = v;
     }
     if (cap < 64) cap = 64;
@@ -255,7 +286,7 @@ QueryLaunch query_launch(const wh_ctx *c, bool base) {
     QueryLaunch q;
     q.polyeval = c->params.circuit == WH_AVERAGE;
     q.waves = q.polyeval ? 4 : (c->params.chunk <= 64 ? 1 : (c->params.chunk <= 128 ? 2 : 4));
-    q.lds = q.polyeval ? 4 * (size_t)z.m * sizeof(F128)
+    q.lds = q.polyeval ? (4 * (size_t)z.m + z.m / 2 + 1) * sizeof(F128)
                        : 48 * (size_t)z.calls + sizeof(QueryShared) + q.waves * (size_t)QT_STAGE_U4 * 16;
     const bool hist = c->params.circuit == WH_HISTOGRAM;
     if (q.polyeval) q.fn = base ? k_query_polyeval<true> : k_query_polyeval<false>;
@@ -320,6 +351,7 @@ int32_t wh_ctx_create(int32_t device_id, const wh_prio3_params *params, wh_ctx *
         if (hipEventCreateWithFlags(&c->ev_h2d[b], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_done[b], hipEventDisableTiming) != hipSuccess) return fail(WH_ERR_HIP);
     c->err.reserve(256);                 // later error texts need no host allocation either
+    knobs_from_env(c->knobs);            // the only look at the environment
     if ((rc = scratch_of_device(c))) return fail(rc);
 
     // constant tables: w^j and s_i = sum_{j=1..calls} w^(ij)
@@ -443,12 +475,23 @@ static int32_t prepare_range(wh_ctx *c, const PrepPlan &pl, const uint8_t *d_blo
         { KTimer t_(c, WH_K_PARSE);
         hipLaunchKernelGGL(k_parse, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, d_blob, d_off + r, nb,
                            d_status + base, tags_b, d_ids + 16 * base, out_b); }
+        if (z.input_len <= c->knobs.v[WH_OPT_CHAIN_MAX_INPUT_LEN]) {
+            // short measurement shares: every sponge of the batch in one launch (chain.hip), then the query
+            { KTimer t_(c, WH_K_CHAIN);
+            launch_chain(c->P, c->W, npad, c->knobs.v[WH_OPT_CHAIN_PREFETCH] != 0, pl.vk0, pl.vk1, c->d_aes, d_ids + 16 * base,
+                         d_status + base, c->stream); }
+            { KTimer t_(c, WH_K_QUERY);
+            hipLaunchKernelGGL(q.fn, dim3(q.polyeval ? (nb + 3) / 4 : nb), dim3(64 * q.waves), q.lds, c->stream, c->P, c->W,
+                               tags_b, out_b, d_status + base); }
+            HIPCHK(c, hipGetLastError());
+            continue;
+        }
         // side stream: the Helpers' proof shares and the hash kernel's job B (hash of the public parts, RLC coefficients,
         // testing ids).  Both are independent of k_meas and run in the wave slots it leaves; what then remains between
         // k_meas and the query kernel is job A alone (3.9 -> 3.2 ms on the critical path, +0.3 ms in k_meas).
         // Neither k_expand nor k_meas writes a status, so job B sees the statuses it would see after them.
-        const bool side = !getenv("WH_NO_SIDE_STREAM");
-        const bool hash_b_side = side && !getenv("WH_HASH_B_MAIN");
+        const bool side = c->knobs.v[WH_OPT_SIDE_STREAM] != 0;
+        const bool hash_b_side = side && c->knobs.v[WH_OPT_HASH_B_SIDE];
         hipStream_t s2 = side ? c->stream2 : c->stream;
         if (side) {
             HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
@@ -460,7 +503,7 @@ static int32_t prepare_range(wh_ctx *c, const PrepPlan &pl, const uint8_t *d_blo
         // stream of its own beside the proof-share expansion (Histogram 3.12 -> 2.92 ms per 100 k reports, Average unchanged).
         // From cfg-1's 2 048 elements on it stays behind the expansion: beside it, it takes wave slots before k_meas has placed
         // its wavefronts (cfg-1: k_meas 16.0 -> 18.3 ms, step 29.5 -> 30.1 ms; sumvec_large loses 0.4-1.5 ms).
-        const bool b_third = hash_b_side && c->z.input_len <= 256 && !getenv("WH_NO_THIRD_STREAM");
+        const bool b_third = hash_b_side && c->z.input_len <= 256 && c->knobs.v[WH_OPT_THIRD_STREAM];
         if (b_third) HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
         if (hash_b_side)
             hipLaunchKernelGGL(k_hash, dim3(npad / 256), dim3(256), 0, b_third ? c->stream3 : s2, c->P, c->W, npad, 1u, pl.vk0, pl.vk1,
@@ -533,7 +576,7 @@ int32_t wh_prio3_prepare_init_batch_dev(wh_ctx *c, const uint8_t verify_key[16],
     // as in the batched path: the Helpers' proof shares on the side stream, the measurement shares and their joint-rand
     // sponges in k_meas (Leader lanes absorb from the key, Helper lane pairs squeeze and absorb in step); keys whose share
     // stream had a rejected chunk go through the general path.  WH_BASE_NO_MEAS keeps the two-pass form (expand, then absorb).
-    const bool paired = !getenv("WH_BASE_NO_MEAS");
+    const bool paired = c->knobs.v[WH_OPT_BASE_PAIRED] != 0;
     if (paired) {
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
@@ -963,7 +1006,7 @@ int32_t wh_prio3_prepare_batch(wh_ctx *c, const uint8_t verify_key[16], const ui
     for (uint64_t i = 0; i < n; i++) if (offsets[i + 1] < offsets[i]) return WH_ERR_PARAM;
     int32_t rc;
     uint64_t chunk_bytes = 2048ull << 20;
-    if (const char *e = getenv("WH_HOST_CHUNK_MB")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 1) chunk_bytes = v << 20; }
+    if (const uint64_t v = c->knobs.v[WH_OPT_HOST_CHUNK_MB]) chunk_bytes = v << 20;
     // chunk boundaries: whole reports, at most chunk_bytes each (a single larger report is a chunk of its own)
     std::vector<uint64_t> first{0};
     uint64_t max_bytes = 0, max_reports = 0;
@@ -997,7 +1040,7 @@ int32_t wh_prio3_prepare_batch(wh_ctx *c, const uint8_t verify_key[16], const ui
     PrepPlan pl;
     if ((rc = prepare_begin(c, verify_key, n, max_reports, c->d_status_own, pl))) return rc;
     unsigned threads = std::thread::hardware_concurrency();
-    if (const char *e = getenv("WH_HOST_COPY_THREADS")) threads = (unsigned)strtoul(e, nullptr, 10);
+    if (const uint64_t v = c->knobs.v[WH_OPT_HOST_COPY_THREADS]) threads = (unsigned)v;
     threads = threads < 1 ? 1 : (threads > 8 ? 8 : threads);
     bool used[2] = {false, false};
     for (uint64_t k = 0; k < nchunks; k++) {
@@ -1135,7 +1178,7 @@ int32_t wh_f128_sum_rows_dev(wh_ctx *c, const uint8_t *d_rows, uint64_t n_rows, 
 static int32_t hh_sum_on(wh_ctx *c, hipStream_t st, const uint32_t *d_buckets, const uint8_t *d_keep, uint64_t n, uint64_t words, uint32_t *d_acc,
                          bool beside = false) {
     if (!n) return WH_OK;
-    static const uint32_t beside_lds = getenv("WH_HH_SUM_LDS") ? (uint32_t)atoi(getenv("WH_HH_SUM_LDS")) : 120u << 10;
+    const uint32_t beside_lds = (uint32_t)c->knobs.v[WH_OPT_HH_SUM_LDS];
     const uint32_t gx = (uint32_t)((words + 4 * 256 - 1) / (4 * 256));
     // enough (x, y) blocks to fill the chip: target ~4096 blocks
     uint32_t gy = 4096 / gx; if (gy < 1) gy = 1; if (gy > n) gy = (uint32_t)n; if (gy > 65535) gy = 65535;
@@ -1240,9 +1283,8 @@ static int32_t hh_eval(wh_ctx *c, const uint8_t verify_key[16], const uint8_t *d
     // sub-batches bound the scratch (64 B per leaf for the proof chain): at most 16384 key chains or 2 GiB at a time
     uint64_t cap = (2ull << 30) / (64ull << depth);
     if (cap > 16384) cap = 16384;
-    if (const char *e = getenv("WH_HH_SUBBATCH")) {       // tuning / test knob: key chains per sub-batch
-        const uint64_t v = strtoull(e, nullptr, 10);
-        if (v >= 1 && v < cap) cap = v;
+    if (const uint64_t v = c->knobs.v[WH_OPT_HH_SUBBATCH]) {       // tuning / test knob: key chains per sub-batch
+        if (v < cap) cap = v;
     }
     if (cap > n) cap = n ? n : 1;
     if ((rc = hh_workspace(c, cap, depth))) return rc;
@@ -1391,6 +1433,20 @@ int32_t wh_hh_aggregate(wh_ctx *c, const uint8_t *keep, uint32_t *acc) {
     if ((rc = wh_hh_aggregate_dev(c, d_keep, c->d_hh_acc, 0))) return rc;
     HIPCHK(c, hipMemcpyAsync(acc, c->d_hh_acc, words * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return WH_OK;
+}
+
+int32_t wh_ctx_set_option(wh_ctx *c, int32_t option, uint64_t value) {
+    if (!c || option < 0 || option >= WH_NUM_OPTS) return WH_ERR_PARAM;
+    WH_LOCK(c);
+    if (option == WH_OPT_HH_SUM_LDS && value > (160u << 10)) return WH_ERR_PARAM;
+    c->knobs.v[option] = value;
+    return WH_OK;
+}
+int32_t wh_ctx_get_option(wh_ctx *c, int32_t option, uint64_t *value) {
+    if (!c || !value || option < 0 || option >= WH_NUM_OPTS) return WH_ERR_PARAM;
+    WH_LOCK(c);
+    *value = c->knobs.v[option];
     return WH_OK;
 }
 

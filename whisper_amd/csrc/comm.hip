@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -38,15 +39,24 @@ struct Rccl {
     std::string why;       // why it could not be loaded
 };
 
-// one binding per process; a copy of RCCL that is already in the process (torch's) is reused
-Rccl *rccl() {
+// one binding per process; a copy of RCCL that is already in the process (torch's) is reused.  WH_RCCL_LIBRARY (read once, at
+// the first use) names the library file for installations that keep RCCL outside the loader's path; when it is set, only
+// that file is tried.
+Rccl &rccl_state() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
-        for (const char *n : names) if ((r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
-        if (!r.handle) for (const char *n : names) if ((r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-        if (!r.handle) { r.why = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed"); return; }
+        const char *defaults[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        const char *override_name = getenv("WH_RCCL_LIBRARY");
+        const char *const *names = override_name ? &override_name : defaults;
+        const int n_names = override_name ? 1 : 4;
+        for (int k = 0; k < n_names && !r.handle; k++) r.handle = dlopen(names[k], RTLD_NOW | RTLD_NOLOAD);
+        std::string last;
+        for (int k = 0; k < n_names && !r.handle; k++) {
+            r.handle = dlopen(names[k], RTLD_NOW | RTLD_GLOBAL);
+            if (!r.handle) { const char *e = dlerror(); last = e ? e : "dlopen failed"; }    // dlerror() clears what it returns
+        }
+        if (!r.handle) { r.why = "RCCL not found: " + last; return; }
 #define WH_SYM(field, name)                                                                    \
         r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, name));                   \
         if (!r.field && r.why.empty()) r.why = std::string("RCCL lacks ") + name
@@ -58,9 +68,10 @@ Rccl *rccl() {
         WH_SYM(error_string, "ncclGetErrorString");
 #undef WH_SYM
     });
-    return r.why.empty() ? &r : nullptr;
+    return r;
 }
-const char *rccl_why() { return "RCCL could not be loaded (librccl.so.1 / librccl.so not found or incomplete)"; }
+Rccl *rccl() { Rccl &r = rccl_state(); return r.why.empty() ? &r : nullptr; }
+const char *rccl_why() { return rccl_state().why.c_str(); }
 
 struct Comm {
     ncclComm_t comm = nullptr;   // nullptr: a lone GPU, no RCCL
@@ -90,6 +101,8 @@ int32_t grow(wh_ctx *c, uint8_t *&p, uint64_t &cap, uint64_t want) {
 }  // namespace
 
 extern "C" {
+
+const char *wh_comm_why(void) { return rccl_why(); }
 
 int32_t wh_comm_unique_id(uint8_t id[WH_COMM_ID_BYTES]) {
     static_assert(sizeof(ncclUniqueId) == WH_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");

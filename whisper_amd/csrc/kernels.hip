@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include "keccak.hpp"
 #include "prio3_dev.hpp"
+#include "tables_dev.hpp"
 #include "f64.hpp"
 
 namespace wh {
@@ -45,26 +46,6 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
     for (int m = 32; m >= 1; m >>= 1) v |= __shfl_xor(v, m, 64);
     return v;
 }
-// x^e for a small per-lane exponent
-__device__ __forceinline__ F128 f_pow_u32(F128 x, uint32_t e) {
-    F128 r = f_one();
-    while (e) {
-        if (e & 1) r = f_mul(r, x);
-        e >>= 1;
-        if (e) x = f_sqr(x);
-    }
-    return r;
-}
-
-// Report handled by slot `slot` of a per-report kernel: the well-formed Leader-role reports
-// first, then the Helper-role ones, so that a wavefront (almost always) holds one role only.
-__device__ __forceinline__ bool report_of_slot(const Workspace &W, uint32_t slot, uint32_t &i) {
-    const uint32_t nl = W.counters[1], nh = W.counters[0];
-    if (slot >= nl + nh) return false;
-    i = slot < nl ? W.llist[slot] : W.hlist[slot - nl];
-    return true;
-}
-
 // --------------------------------------------------------------------------------- parse ----
 // VdafBatchedKey::decode_with_param (vdaf.rs:164-192) as far as structure goes: lengths,
 // agg_id, num_queries.  Field-element range checks happen where the elements are loaded
@@ -131,70 +112,6 @@ __global__ void k_parse(Prio3Dev P, Workspace W, const uint8_t *blob, const uint
 
 // (the Helper expansion kernel lives in expand.hip: hipcc 7.2 crashes in its inliner when this
 // translation unit holds both sponge kernels)
-
-// Per-report constants of the query kernels, computed by the lane that derived the randomness:
-// barycentric weights L_j(r) = (r^m - 1)/m * w^j / (r - w^j), j = 0..calls, w = omega_m (one
-// inversion per report: prefix products of (r - w^j) are parked in the weight row), and for the
-// ParallelSum circuits the weights as limbs and small power tables of rho and r.
-__device__ __forceinline__ void weights_and_tables(const Prio3Dev &P, const Workspace &W, uint32_t i, const F128 &r,
-                                                   const F128 &rm, const F128 &rho) {
-    // Barycentric weights for run 2 (run 1's verifier never reaches the tag, prio3.rs:2713):
-    //   L_j(r) = (r^m - 1)/m * w^j / (r - w^j),  j = 0..calls,  w = omega_m.
-    // One inversion per report: prefix products of (r - w^j) are parked in the weight row.
-    F128 *L = W.weights + (uint64_t)i * P.n_weights;
-    F128 acc = f_one();
-    for (uint32_t j = 0; j < P.n_weights; j++) {
-        L[j] = acc;
-        acc = f_mul(acc, f_sub(r, P.omega[j]));
-    }
-    // the common factor (r^m - 1)/m rides on the running inverse: three multiplications per weight
-    F128 inv = f_mul(f_inv(acc), f_mul(f_sub(rm, f_one()), P.m_inv));
-    F128 parked = L[P.n_weights - 1];          // the next prefix product is fetched a step ahead of its use
-    for (uint32_t j = P.n_weights; j-- > 0;) {
-        F128 w = P.omega[j];
-        const F128 pre = parked;
-        if (j) parked = L[j - 1];
-        F128 dinv = f_mul(inv, pre);           // (r^m - 1)/m / (r - w^j)
-        inv = f_mul(inv, f_sub(r, w));
-        L[j] = f_mul(w, dinv);
-    }
-    if (P.circuit != CIRCUIT_AVERAGE) {
-        // what the query kernel would otherwise compute with a whole wavefront per value:
-        // small power tables of rho and r, and the weights as limbs with
-        // M_j = L_j rho^(chunk (j-1)) next to L_j
-        RepPow *pw = &W.pows[i];
-        F128 t = rho;
-        for (int q = 0; q < 8; q++) { pw->rho_lo[q] = t; if (q < 7) t = f_mul(t, rho); }
-        F128 u = f_one();
-        for (int q = 0; q < 8; q++) { pw->rho_hi[q] = u; u = f_mul(u, t); }     // t = rho^8
-        const F128 u2 = f_sqr(u);                                               // u = rho^64
-        pw->rho64[0] = f_one(); pw->rho64[1] = u; pw->rho64[2] = u2; pw->rho64[3] = f_mul(u2, u); pw->rho64[4] = f_sqr(u2);
-        t = f_one();
-        for (int q = 0; q < 8; q++) { pw->r_lo[q] = t; t = f_mul(t, r); }
-        u = f_one();
-        for (int q = 0; q < 8; q++) { pw->r_hi[q] = u; u = f_mul(u, t); }       // t = r^8
-        pw->r64 = u;
-        const F128 rc = f_pow_u32(rho, P.chunk);
-        uint4 *wl = reinterpret_cast<uint4 *>(W.wlimbs + (uint64_t)i * 12 * P.calls);
-        F128 pj = f_one(), sumL = f_zero();
-        F128 lnext = L[1];
-        for (uint32_t j = 1; j <= P.calls; j++) {
-            const F128 l = lnext;
-            if (j < P.calls) lnext = L[j + 1];
-            const F128 m = f_mul(l, pj);
-            sumL = f_add(sumL, l);
-            uint32_t tl[5], tm[5];
-            f_split26(l, tl);
-            f_split26(m, tm);
-            wl[3 * (j - 1)] = make_uint4(tl[0], tl[1], tl[2], tl[3]);
-            wl[3 * (j - 1) + 1] = make_uint4(tl[4], tm[0], tm[1], tm[2]);
-            wl[3 * (j - 1) + 2] = make_uint4(tm[3], tm[4], 0, 0);
-            pj = f_mul(pj, rc);
-        }
-        pw->L0 = L[0];
-        pw->h_sumL = f_mul(P.half, sumL);
-    }
-}
 
 // ---------------------------------------------------------------------------------- hash ----
 // Three wavefronts a SIMD (168 VGPRs).  Register prefetch of the next rate block: it lost while jobs A and B shared one launch
@@ -290,34 +207,7 @@ __global__ void __launch_bounds__(256) WH_HASH_ATTR k_hash(Prio3Dev P, Workspace
         if (f_eq(r1m, f_one()) || f_eq(rm, f_one())) { status[i] = ST_ERR_QUERY_RAND; return; }
         weights_and_tables(P, W, i, r, rm, sc->jr[P.jr_len]);
     } else {
-        // testing id: AES128_vk(client_id.to_le_bytes()) (main.rs:51, common/src/prg.rs:650-655)
-        const uint8_t *sbox = aes_rk + 176;
-        uint8_t st[16], t[16];
-#pragma unroll
-        for (int b = 0; b < 16; b++) st[b] = d.base[15 - b] ^ aes_rk[b];
-#pragma unroll 1
-        for (int round = 1; round <= 10; round++) {
-#pragma unroll
-            for (int c = 0; c < 4; c++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) t[4 * c + r] = sbox[st[4 * ((c + r) & 3) + r]];
-            if (round < 10) {
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    uint8_t b0 = t[4 * c], b1 = t[4 * c + 1], b2 = t[4 * c + 2], b3 = t[4 * c + 3];
-#define XT(x) ((uint8_t)(((x) << 1) ^ ((((x) >> 7) & 1) * 0x1b)))
-                    t[4 * c] = XT(b0) ^ XT(b1) ^ b1 ^ b2 ^ b3;
-                    t[4 * c + 1] = b0 ^ XT(b1) ^ XT(b2) ^ b2 ^ b3;
-                    t[4 * c + 2] = b0 ^ b1 ^ XT(b2) ^ XT(b3) ^ b3;
-                    t[4 * c + 3] = XT(b0) ^ b0 ^ b1 ^ b2 ^ XT(b3);
-#undef XT
-                }
-            }
-#pragma unroll
-            for (int b = 0; b < 16; b++) st[b] = t[b] ^ aes_rk[16 * round + b];
-        }
-#pragma unroll
-        for (int b = 0; b < 16; b++) testing_ids[16ull * i + b] = st[b];
+        aes_testing_id(aes_rk, d.base, testing_ids + 16ull * i);
     }
 }
 
@@ -953,11 +843,27 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WH_Q_W
 //   v[1] = L_0 proof[0] + sum_j L_j x_{j-1}    -- the single wire polynomial at r
 //   v[2] = G(r)
 // decide on a public proof: pp[0] == 0 and pp[1]^2 - pp[1] == pp[2].
+// Shape of the work: every load of the report is issued before the first use (one memory latency, not one per phase);
+// the powers of rho and r come from the tables the chain / hash lane left (RepPow), never from a per-lane
+// exponentiation; G(r) is Horner over the <= 4 coefficients of a lane times r^lane; the four 64-lane sums (G(r), v[0], v[1],
+// the out share) go through one reduce-scatter (7 additions instead of 24); the last step's eight products and checks
+// sit in eight lanes side by side (one multiplication deep) instead of one lane doing ten in a row.
+__device__ __forceinline__ F128 sel_f(bool c, const F128 &a, const F128 &b) { return F128{c ? a.lo : b.lo, c ? a.hi : b.hi}; }
+__device__ __forceinline__ F128 readlane_f(const F128 &v, int l) {
+    const uint32_t a = __builtin_amdgcn_readlane((int)(uint32_t)v.lo, l), b = __builtin_amdgcn_readlane((int)(uint32_t)(v.lo >> 32), l);
+    const uint32_t c = __builtin_amdgcn_readlane((int)(uint32_t)v.hi, l), d = __builtin_amdgcn_readlane((int)(uint32_t)(v.hi >> 32), l);
+    return F128{a | ((uint64_t)b << 32), c | ((uint64_t)d << 32)};
+}
 template <bool BASE>
 __global__ void __launch_bounds__(256) k_query_polyeval(Prio3Dev P, Workspace W, uint8_t *tags,
                                                         uint8_t *out_shares, int32_t *status) {
     extern __shared__ F128 lds[];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t m = P.m, lg = P.log2m, calls = P.calls;
+    // w^k, k < m / 2, for the butterflies: once per workgroup
+    F128 *tw = lds + 4ull * m;
+    for (uint32_t k = threadIdx.x; k < (m >> 1); k += blockDim.x) tw[k] = P.omega[k];
+    __syncthreads();
     const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + wave;
     uint32_t i;
     if (!report_of_slot(W, slot, i)) return;
@@ -972,109 +878,159 @@ __global__ void __launch_bounds__(256) k_query_polyeval(Prio3Dev P, Workspace W,
         }
         return;
     }
-    const uint32_t m = P.m;
     F128 *buf = lds + (uint64_t)wave * m;
     const RepDesc d = W.desc[i];
     const RepScal *sc = &W.scal[i];
+    const RepPow *pw = &W.pows[i];
     const uint8_t *pp0 = d.tail + 40, *pp1 = pp0 + 16ull * P.verifier_len;
-    const F128 *rlc = W.rlc + (uint64_t)i * (P.verifier_len + 5);
-    const F128 *Lg = W.weights + (uint64_t)i * P.n_weights;
-    const F128 r = sc->qr[1], rho = sc->jr[P.jr_len];
+    const uint8_t *rlc = reinterpret_cast<const uint8_t *>(W.rlc + (uint64_t)i * (P.verifier_len + 5));
+    const uint8_t *Lg = reinterpret_cast<const uint8_t *>(W.weights + (uint64_t)i * P.n_weights);
     const bool leader = d.role == 0;
     uint32_t bad = 0;
 
+    // ---- all loads of the report ----
+    const uint8_t *G = d.proof2 + 16ull * P.arity;
+    F128 gc[4];                                     // G_e, e = lane + 64 u  (gpoly_len = 2 m - 1 <= 255)
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const uint32_t e = lane + 64 * u;
+        gc[u] = ld128g(G + 16ull * (e < P.gpoly_len ? e : 0));
+        if (e >= P.gpoly_len) gc[u] = f_zero();
+    }
+    F128 xv[2], lw[2];                              // x_(j-1) and L_j, j = 1 + lane + 64 u
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const uint32_t j = 1 + lane + 64 * u, jc = j <= calls ? j : 1;
+        xv[u] = ld128g(d.meas + 16ull * (jc - 1));
+        lw[u] = ld128g(Lg + 16ull * jc);
+        if (j > calls) xv[u] = f_zero();
+    }
+    const F128 seed0 = ld128g(d.proof2), L0 = ld128g(Lg);
+    const F128 rho_a = pw->rho_lo[lane & 7], rho_b = pw->rho_hi[lane >> 3], rho64 = pw->rho64[1];   // rho^((lane & 7) + 1), rho^(8 (lane >> 3))
+    const F128 r_a = pw->r_lo[lane & 7], r_b = pw->r_hi[lane >> 3], r64 = pw->r64;
+    // the last step, one operand set per lane e < 8:
+    //   e = 0..2  rlc[e] * (ver[e] - pp1[e])       e = 3, 4  decide(pp0 / pp1) -> rlc[e] or 0
+    //   e = 5, 6  rand_diff[e - 5] -> rlc[e] or 0   e = 7     rlc[7] * (+-hash)
+    const uint32_t te = lane & 7;
+    F128 t_rlc = f_zero(), t_a = f_zero(), t_b = f_zero(), t_c = f_zero();
+    uint32_t t_flag = 0;
+    if (!BASE) {
+        t_rlc = ld128g(rlc + 16ull * te);
+        const uint8_t *pp = te == 3 ? pp0 : pp1;
+        t_a = ld128g(pp + 16ull * (te < 3 ? te : 0));          // e < 3: pp1[e];  e = 3, 4: pp[0]
+        t_b = ld128g(pp + 16);
+        t_c = ld128g(pp + 32);
+        t_flag = sc->rand_diff[te == 6];
+        if (te == 7) t_b = sc->hash;
+    }
     if (!BASE && leader)
-        for (uint32_t e = lane; e < P.proof_len; e += 64) {
-            F128 v = ld128(d.proof1 + 16ull * e);
+        for (uint32_t e = lane; e < P.proof_len; e += 64) {       // proof share of run 1: hashed, never evaluated, but it has to decode
+            const F128 v = ld128g(d.proof1 + 16ull * e);
             bad |= !f_in_range(v.lo, v.hi);
         }
-    // G = proof2[1 ..]: G(r), and G folded mod (X^m - 1) into LDS in bit-reversed order
-    const uint8_t *G = d.proof2 + 16ull * P.arity;
-    F128 g_at_r = f_zero();
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- G folded mod (X^m - 1) into LDS, bit-reversed; G(r) = sum_lane r^lane Horner_{r^64}(G_lane, G_lane+64, ...) ----
+#pragma unroll
+    for (int u = 0; u < 4; u++) bad |= !f_in_range(gc[u].lo, gc[u].hi);
     {
-        F128 rpow = f_pow_u32(r, lane), r64 = f_sqr_n(r, 6);
-        for (uint32_t e = lane; e < P.gpoly_len; e += 64) {
-            F128 c = ld128(G + 16ull * e);
-            bad |= !f_in_range(c.lo, c.hi);
-            g_at_r = f_add(g_at_r, f_mul(c, rpow));
-            rpow = f_mul(rpow, r64);
-        }
+        // coefficient e + m sits in slot u + 2 (m = 128), in slot 1 (m = 64), or in lane e + m's slot 0 (m <= 32); slots
+        // past the polynomial's end hold zero
+        F128 up = gc[1];
+        if (m < 64) up = F128{__shfl((unsigned long long)gc[0].lo, (int)((lane + m) & 63), 64), __shfl((unsigned long long)gc[0].hi, (int)((lane + m) & 63), 64)};
+        const F128 fold0 = f_add(gc[0], m == 128 ? gc[2] : up);
+        if (lane < m) buf[__brev(lane) >> (32 - lg)] = fold0;
+        if (m == 128) buf[__brev(lane + 64) >> (32 - lg)] = f_add(gc[1], gc[3]);
     }
-    g_at_r = wave_sum(g_at_r);
-    for (uint32_t e = lane; e < m; e += 64) {
-        F128 c = ld128(G + 16ull * e);
-        if (e + m < P.gpoly_len) c = f_add(c, ld128(G + 16ull * (e + m)));
-        buf[__brev(e) >> (32 - P.log2m)] = c;
+    F128 g_p = gc[0];
+    if (P.gpoly_len > 64) {            // uniform
+        g_p = gc[1];
+        if (P.gpoly_len > 128) g_p = f_add(f_mul(f_add(f_mul(gc[3], r64), gc[2]), r64), gc[1]);
+        g_p = f_add(f_mul(g_p, r64), gc[0]);
     }
-    // in-place radix-2 NTT, one butterfly per lane and stage (m / 2 <= 64 butterflies)
-    for (uint32_t l = 1; l <= P.log2m; l++) {
+    g_p = f_mul(g_p, f_mul(r_a, r_b));                                          // r^lane
+    // ---- in-place radix-2 NTT, one butterfly per lane and stage (m / 2 <= 64 butterflies) ----
+    for (uint32_t l = 1; l <= lg; l++) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
         const uint32_t half = 1u << (l - 1);
         if (lane < (m >> 1)) {
-            uint32_t k = lane & (half - 1), base = ((lane >> (l - 1)) << l) + k;
-            F128 u = buf[base], v = f_mul(buf[base + half], P.omega[k << (P.log2m - l)]);
+            const uint32_t k = lane & (half - 1), base = ((lane >> (l - 1)) << l) + k;
+            const F128 u = buf[base], v = f_mul(buf[base + half], tw[k << (lg - l)]);
             buf[base] = f_add(u, v);
             buf[base + half] = f_sub(u, v);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    F128 v0 = f_zero(), v1 = f_zero();
-    for (uint32_t j = 1 + lane; j <= P.calls; j += 64) {
-        F128 x = ld128(d.meas + 16ull * (j - 1));
-        bad |= !f_in_range(x.lo, x.hi);
-        v0 = f_add(v0, f_mul(f_pow_u32(rho, j), buf[j]));
-        v1 = f_add(v1, f_mul(Lg[j], x));
+    // ---- v[0], v[1], truncate (field.rs:256-269): terms j = 1 + lane (+ 64) ----
+    F128 v0_p = f_zero(), v1_p = f_zero(), out_p = f_zero();
+    const F128 rp = f_mul(rho_a, rho_b);                                        // rho^(lane + 1)
+    {
+        const uint32_t j = 1 + lane;
+        bad |= !f_in_range(xv[0].lo, xv[0].hi);
+        const F128 a0 = f_mul(rp, buf[j <= calls ? j : 0]), a1 = f_mul(lw[0], xv[0]);
+        const F128 a2 = f_mul(lane < 64 ? F128{1ull << lane, 0} : f_zero(), xv[0]);
+        if (j <= calls) { v0_p = a0; v1_p = a1; out_p = a2; }
     }
-    v0 = wave_sum(v0);
-    F128 seed0 = ld128(d.proof2);
+    if (calls > 64) {                  // uniform: bits up to 127
+        const uint32_t j = 65 + lane;
+        bad |= !f_in_range(xv[1].lo, xv[1].hi);
+        const F128 a0 = f_mul(f_mul(rp, rho64), buf[j <= calls ? j : 0]), a1 = f_mul(lw[1], xv[1]);
+        const F128 a2 = f_mul(F128{0, 1ull << lane}, xv[1]);
+        if (j <= calls) { v0_p = f_add(v0_p, a0); v1_p = f_add(v1_p, a1); out_p = f_add(out_p, a2); }
+    }
     bad |= !f_in_range(seed0.lo, seed0.hi);
-    v1 = f_add(wave_sum(v1), f_mul(Lg[0], seed0));
-
-    // truncate: sum_l 2^l x_l (field.rs:256-269)
-    F128 out = f_zero();
-    for (uint32_t l = lane; l < P.bits; l += 64) {
-        F128 w = l < 64 ? F128{1ull << l, 0} : F128{0, 1ull << (l - 64)};
-        out = f_add(out, f_mul(w, ld128(d.meas + 16ull * l)));
+    {
+        const F128 sterm = f_mul(L0, seed0);                                    // the wire's seed (call 0)
+        if (lane == 0) v1_p = f_add(v1_p, sterm);
     }
-    out = wave_sum(out);
-
-    F128 tag = f_zero();
+    // ---- the four sums in one reduce-scatter: rows of 16 lanes end up with G(r), v[0], v[1], out ----
+    F128 red;
+    {
+        const bool h5 = lane & 32, h4 = lane & 16;
+        F128 ka = f_add(sel_f(h5, v1_p, g_p), shfl_xor_f(sel_f(h5, g_p, v1_p), 32));
+        F128 kb = f_add(sel_f(h5, out_p, v0_p), shfl_xor_f(sel_f(h5, v0_p, out_p), 32));
+        red = f_add(sel_f(h4, kb, ka), shfl_xor_f(sel_f(h4, ka, kb), 16));
+#pragma unroll
+        for (int msk = 8; msk >= 1; msk >>= 1) red = f_add(red, shfl_xor_f(red, msk));
+    }
+    const F128 g_at_r = readlane_f(red, 0), v0 = readlane_f(red, 16), v1 = readlane_f(red, 32);
+    F128 out = readlane_f(red, 48);
     if (BASE) {
         bad = wave_or(bad);
         if (lane == 0) {
-            if (bad) { status[i] = ST_ERR_MODULUS; out = f_zero(); v0 = v1 = g_at_r = f_zero(); }
+            F128 a0 = v0, a1 = v1, a2 = g_at_r;
+            if (bad) { status[i] = ST_ERR_MODULUS; out = f_zero(); a0 = a1 = a2 = f_zero(); }
             out_row[0] = out;
-            ver_row[0] = v0; ver_row[1] = v1; ver_row[2] = g_at_r;
+            ver_row[0] = a0; ver_row[1] = a1; ver_row[2] = a2;
             if (P.ver_stride > 3) ver_row[3] = bad ? f_zero() : sc->own;
         }
         return;
     }
-    if (lane == 0) {
-        F128 ver[3] = {v0, v1, g_at_r};
-        F128 dec[2];
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-            const uint8_t *pp = t ? pp1 : pp0;
-            F128 a = ld128(pp), b = ld128(pp + 16), c = ld128(pp + 32);
-            bad |= !f_in_range(a.lo, a.hi) | !f_in_range(b.lo, b.hi) | !f_in_range(c.lo, c.hi);
-            bool ok = f_is_zero(a) && f_eq(f_sub(f_sqr(b), b), c);
-            dec[t] = ok ? f_zero() : f_one();
-        }
-#pragma unroll
-        for (int e = 0; e < 3; e++) {
-            F128 dv = leader ? f_sub(ver[e], ld128(pp1 + 16 * e)) : ver[e];
-            tag = f_add(tag, f_mul(rlc[e], dv));
-        }
-        tag = f_add(tag, f_mul(rlc[3], dec[0]));
-        tag = f_add(tag, f_mul(rlc[4], dec[1]));
-        if (sc->rand_diff[0]) tag = f_add(tag, rlc[5]);
-        if (sc->rand_diff[1]) tag = f_add(tag, rlc[6]);
-        tag = f_add(tag, f_mul(rlc[7], leader ? f_neg(sc->hash) : sc->hash));
+    // ---- differences, decide, RLC tag (prio3.rs:2703-2871), eight lanes side by side ----
+    const bool dec_lane = te == 3 || te == 4;
+    F128 ma = t_rlc, mb;
+    {
+        const F128 ver = te == 0 ? v0 : (te == 1 ? v1 : g_at_r);
+        const F128 dv = leader ? f_sub(ver, t_a) : ver;
+        mb = te < 3 ? dv : (leader ? f_neg(t_b) : t_b);                          // e = 7: share of zero, Leader -H, Helper +H (:2844-2855)
+        if (dec_lane) { ma = t_b; mb = t_b; }                                    // pp[1]^2
+        if (te < 5) bad |= !f_in_range(t_a.lo, t_a.hi);
+        if (dec_lane) bad |= !f_in_range(t_b.lo, t_b.hi) | !f_in_range(t_c.lo, t_c.hi);
     }
+    F128 term = f_mul(ma, mb);
+    if (dec_lane) {
+        const bool ok = f_is_zero(t_a) && f_eq(f_sub(term, t_b), t_c);
+        term = ok ? f_zero() : t_rlc;
+    } else if (te == 5 || te == 6) {
+        term = t_flag ? t_rlc : f_zero();
+    }
+#pragma unroll
+    for (int msk = 4; msk >= 1; msk >>= 1) term = f_add(term, shfl_xor_f(term, msk));
     bad = wave_or(bad);
     if (lane == 0) {
+        F128 tag = term;
         if (bad) { status[i] = ST_ERR_MODULUS; tag = f_zero(); out = f_zero(); }
         out_row[0] = out;
         st128(tag_out, leader ? tag : f_neg(tag));

@@ -10,7 +10,7 @@ import hashlib
 
 import numpy as np
 
-from ._lib import lib, WhError
+from ._lib import lib, WhError, OPTIONS
 from .prio3 import KERNELS
 
 BUCKET_WORDS = 258  # STRING_SIZE + 2
@@ -121,6 +121,10 @@ class HeavyHitters:
 
     def synchronize(self):
         self._chk(lib.wh_ctx_synchronize(self._ctx), "synchronize")
+
+    def set_option(self, name, value):
+        """wh_ctx_set_option: a tuning / test knob of this context (names: whisper_amd._lib.OPTIONS)."""
+        self._chk(lib.wh_ctx_set_option(self._ctx, OPTIONS[name], int(value)), f"set_option({name})")
 
     def eval_and_check(self, verify_key, key_chains):
         """key_chains: uint8 [n, stride >= key_len].  Returns (tags [n] of 64-char str, testing_ids [n] int, status int32[n]);

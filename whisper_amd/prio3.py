@@ -10,7 +10,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import lib, Params, Sizes, WhError
+from ._lib import lib, Params, Sizes, WhError, OPTIONS
 
 SUMVEC, HISTOGRAM, AVERAGE = 0, 1, 2
 P128 = 2**128 - 7 * 2**66 + 1
@@ -82,7 +82,7 @@ def shard_batched_many(params, measurements, nonces, rands, first_client_id=0, n
 
 
 # indices WH_K_* of wh_ctx_kernel_times
-KERNELS = ("parse", "expand", "hash", "query", "aggregate", "hh_sum", "meas", "hh_main", "hh_support", "hh_chain", "hh_final", "prove", "sort")
+KERNELS = ("parse", "expand", "hash", "query", "aggregate", "hh_sum", "meas", "hh_main", "hh_support", "hh_chain", "hh_final", "prove", "sort", "chain")
 
 
 class Prio3:
@@ -118,6 +118,15 @@ class Prio3:
 
     def synchronize(self):
         self._chk(lib.wh_ctx_synchronize(self._ctx), "synchronize")
+
+    def set_option(self, name, value):
+        """wh_ctx_set_option: a tuning / test knob of this context (names: whisper_amd._lib.OPTIONS)."""
+        self._chk(lib.wh_ctx_set_option(self._ctx, OPTIONS[name], int(value)), f"set_option({name})")
+
+    def get_option(self, name):
+        v = C.c_uint64()
+        self._chk(lib.wh_ctx_get_option(self._ctx, OPTIONS[name], C.byref(v)), f"get_option({name})")
+        return v.value
 
     def output_len(self):
         return self.sizes.output_len
