@@ -379,7 +379,9 @@ enum {
     WH_OPT_CHAIN_MAX_INPUT_LEN = 9, /* WH_CHAIN_MAX_INPUT_LEN: circuits with input_len up to this run all their sponges in one
                                      * launch (chain.hip) instead of the k_meas pipeline */
     WH_OPT_CHAIN_PREFETCH = 10,     /* WH_CHAIN_PREFETCH: 1 = that launch keeps the next rate block's loads in flight (3 waves/SIMD) */
-    WH_NUM_OPTS = 11
+    WH_OPT_QUERY_TINY = 11,         /* WH_QUERY_TINY: 0 = circuits of at most two gadget calls of at most 64 slots take the general
+                                     * query kernel instead of the one-wavefront-per-report one */
+    WH_NUM_OPTS = 12
 };
 #define WH_CHAIN_MAX_INPUT_LEN_DEFAULT 2048u
 int32_t wh_ctx_set_option(wh_ctx *ctx, int32_t option, uint64_t value);

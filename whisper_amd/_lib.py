@@ -136,4 +136,4 @@ lib.wh_comm_why.restype = C.c_char_p
 
 # WH_OPT_* of wh_ctx_set_option (include/whisper_gfx950.h)
 OPTIONS = {"max_subbatch": 0, "host_chunk_mb": 1, "host_copy_threads": 2, "hh_subbatch": 3, "hh_sum_lds": 4, "side_stream": 5,
-           "hash_b_side": 6, "third_stream": 7, "base_paired": 8, "chain_max_input_len": 9, "chain_prefetch": 10}
+           "hash_b_side": 6, "third_stream": 7, "base_paired": 8, "chain_max_input_len": 9, "chain_prefetch": 10, "query_tiny": 11}

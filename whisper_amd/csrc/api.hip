@@ -52,6 +52,7 @@ static void knobs_from_env(Knobs &k) {
     k.v[WH_OPT_BASE_PAIRED] = 1;
     k.v[WH_OPT_CHAIN_MAX_INPUT_LEN] = WH_CHAIN_MAX_INPUT_LEN_DEFAULT;
     k.v[WH_OPT_CHAIN_PREFETCH] = 0;
+    k.v[WH_OPT_QUERY_TINY] = 1;
     auto num = [](const char *name, uint64_t &out) { if (const char *e = getenv(name)) out = strtoull(e, nullptr, 10); };
     num("WH_MAX_SUBBATCH", k.v[WH_OPT_MAX_SUBBATCH]);
     num("WH_HOST_CHUNK_MB", k.v[WH_OPT_HOST_CHUNK_MB]);
@@ -60,6 +61,7 @@ static void knobs_from_env(Knobs &k) {
     num("WH_HH_SUM_LDS", k.v[WH_OPT_HH_SUM_LDS]);
     num("WH_CHAIN_MAX_INPUT_LEN", k.v[WH_OPT_CHAIN_MAX_INPUT_LEN]);
     num("WH_CHAIN_PREFETCH", k.v[WH_OPT_CHAIN_PREFETCH]);
+    num("WH_QUERY_TINY", k.v[WH_OPT_QUERY_TINY]);
     if (getenv("WH_NO_SIDE_STREAM")) k.v[WH_OPT_SIDE_STREAM] = 0;
     if (getenv("WH_HASH_B_MAIN")) k.v[WH_OPT_HASH_B_SIDE] = 0;
     if (getenv("WH_NO_THIRD_STREAM")) k.v[WH_OPT_THIRD_STREAM] = 0;
@@ -280,21 +282,27 @@ uint64_t pick_cap(const wh_ctx *c, uint64_t n) {
 // one workgroup per report, one wavefront per 64 gadget slots (at most four); LDS holds 48 B of
 // weight limbs per gadget call, the hand-over area and the truncate staging of each wave.
 typedef void (*query_fn)(Prio3Dev, Workspace, uint8_t *, uint8_t *, int32_t *);
-struct QueryLaunch { query_fn fn; uint32_t waves; size_t lds; bool polyeval; };
+struct QueryLaunch { query_fn fn; uint32_t waves; size_t lds; uint32_t per_block; };     // per_block: reports per workgroup
 QueryLaunch query_launch(const wh_ctx *c, bool base) {
     const HostSizes &z = c->z;
     QueryLaunch q;
-    q.polyeval = c->params.circuit == WH_AVERAGE;
-    q.waves = q.polyeval ? 4 : (c->params.chunk <= 64 ? 1 : (c->params.chunk <= 128 ? 2 : 4));
-    q.lds = q.polyeval ? (4 * (size_t)z.m + z.m / 2 + 1) * sizeof(F128)
-                       : 48 * (size_t)z.calls + sizeof(QueryShared) + q.waves * (size_t)QT_STAGE_U4 * 16;
+    const bool polyeval = c->params.circuit == WH_AVERAGE;
     const bool hist = c->params.circuit == WH_HISTOGRAM;
-    if (q.polyeval) q.fn = base ? k_query_polyeval<true> : k_query_polyeval<false>;
+    // a few gadget calls of at most 64 slots: one wavefront per report, everything in registers (k_query_psum_tiny)
+    const bool tiny = !polyeval && c->params.chunk <= 64 && z.calls <= QTINY_MAX_CALLS && c->knobs.v[WH_OPT_QUERY_TINY];
+    q.per_block = polyeval || tiny ? 4 : 1;
+    q.waves = polyeval || tiny ? 4 : (c->params.chunk <= 64 ? 1 : (c->params.chunk <= 128 ? 2 : 4));
+    q.lds = polyeval ? (4 * (size_t)z.m + z.m / 2 + 1) * sizeof(F128)
+                     : (tiny ? 0 : 48 * (size_t)z.calls + sizeof(QueryShared) + q.waves * (size_t)QT_STAGE_U4 * 16);
+    if (polyeval) q.fn = base ? k_query_polyeval<true> : k_query_polyeval<false>;
+    else if (tiny) q.fn = base ? (hist ? k_query_psum_tiny<true, true> : k_query_psum_tiny<false, true>)
+                               : (hist ? k_query_psum_tiny<true, false> : k_query_psum_tiny<false, false>);
     else if (base) q.fn = hist ? k_query_psum<true, true> : k_query_psum<false, true>;
     else q.fn = hist ? k_query_psum<true, false> : k_query_psum<false, false>;
     if (q.lds > 64 * 1024) q.fn = nullptr;
     return q;
 }
+static inline dim3 query_grid(const QueryLaunch &q, uint32_t nb) { return dim3((nb + q.per_block - 1) / q.per_block); }
 
 }  // namespace
 
@@ -481,7 +489,7 @@ static int32_t prepare_range(wh_ctx *c, const PrepPlan &pl, const uint8_t *d_blo
             launch_chain(c->P, c->W, npad, c->knobs.v[WH_OPT_CHAIN_PREFETCH] != 0, pl.vk0, pl.vk1, c->d_aes, d_ids + 16 * base,
                          d_status + base, c->stream); }
             { KTimer t_(c, WH_K_QUERY);
-            hipLaunchKernelGGL(q.fn, dim3(q.polyeval ? (nb + 3) / 4 : nb), dim3(64 * q.waves), q.lds, c->stream, c->P, c->W,
+            hipLaunchKernelGGL(q.fn, query_grid(q, nb), dim3(64 * q.waves), q.lds, c->stream, c->P, c->W,
                                tags_b, out_b, d_status + base); }
             HIPCHK(c, hipGetLastError());
             continue;
@@ -521,7 +529,7 @@ static int32_t prepare_range(wh_ctx *c, const PrepPlan &pl, const uint8_t *d_blo
         hipLaunchKernelGGL(k_hash, dim3((hash_b_side ? 1 : 2) * npad / 256), dim3(256), 0, c->stream, c->P, c->W, npad,
                            hash_b_side ? 0u : 2u, pl.vk0, pl.vk1, c->d_aes, d_ids + 16 * base, d_status + base); }
         { KTimer t_(c, WH_K_QUERY);
-        hipLaunchKernelGGL(q.fn, dim3(q.polyeval ? (nb + 3) / 4 : nb), dim3(64 * q.waves), q.lds, c->stream, c->P, c->W,
+        hipLaunchKernelGGL(q.fn, query_grid(q, nb), dim3(64 * q.waves), q.lds, c->stream, c->P, c->W,
                            tags_b, out_b, d_status + base); }
         HIPCHK(c, hipGetLastError());
     }
@@ -595,7 +603,7 @@ int32_t wh_prio3_prepare_init_batch_dev(wh_ctx *c, const uint8_t verify_key[16],
     { KTimer t_(c, WH_K_HASH);
     hipLaunchKernelGGL(k_hash_base, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, vk0, vk1, d_status, paired ? 1u : 0u); }
     { KTimer t_(c, WH_K_QUERY);
-    hipLaunchKernelGGL(q.fn, dim3(q.polyeval ? (nb + 3) / 4 : nb), dim3(64 * q.waves), q.lds, c->stream, c->P, c->W, d_prep,
+    hipLaunchKernelGGL(q.fn, query_grid(q, nb), dim3(64 * q.waves), q.lds, c->stream, c->P, c->W, d_prep,
                        d_out, d_status); }
     HIPCHK(c, hipGetLastError());
     if ((rc = remember_status(c, d_status, n))) return rc;
@@ -680,7 +688,7 @@ static int32_t flp_query_dev(wh_ctx *c, const uint8_t *d_in, const uint8_t *d_pf
     HIPCHK(c, hipMemsetAsync(c->W.counters, 0, 64, c->stream));
     const uint32_t nb = (uint32_t)n, npad = (nb + 255) / 256 * 256;
     hipLaunchKernelGGL(k_flp_setup, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, d_in, d_pf, d_qr, d_jr, nb, d_status);
-    hipLaunchKernelGGL(q.fn, dim3(q.polyeval ? (nb + 3) / 4 : nb), dim3(64 * q.waves), q.lds, c->stream, c->P, c->W, d_ver,
+    hipLaunchKernelGGL(q.fn, query_grid(q, nb), dim3(64 * q.waves), q.lds, c->stream, c->P, c->W, d_ver,
                        reinterpret_cast<uint8_t *>(c->d_out_shares), d_status);
     HIPCHK(c, hipGetLastError());
     return WH_OK;

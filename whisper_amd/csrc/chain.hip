@@ -27,7 +27,8 @@ enum : uint32_t {
     CS_HASH, CS_HASH_ELEM, CS_RLC, CS_END
 };
 
-template <bool PREFETCH>
+// PRIO: SpongeT's priority mode (keccak.hpp)
+template <bool PREFETCH, int PRIO>
 __device__ __forceinline__ void chain_body(const Prio3Dev &P, const Workspace &W, uint32_t npad, uint64_t vk0, uint64_t vk1,
                                            const uint8_t *aes_rk, uint8_t *testing_ids, int32_t *status) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -59,7 +60,8 @@ __device__ __forceinline__ void chain_body(const Prio3Dev &P, const Workspace &W
     const uint8_t *nonce = qr_blind + 16;
     const uint32_t njr = 2 * P.jr_len;
     uint8_t *own = reinterpret_cast<uint8_t *>(&sc->own);
-    SpongeG s;
+    SpongeT<true, PRIO> s;
+    s.slot = PRIO < 0 ? wave_slot() : 0;
     F128 sd = f_zero();
 #pragma unroll 1
     for (uint32_t stg = first; stg <= last; stg++) {
@@ -133,16 +135,26 @@ __device__ __forceinline__ void chain_body(const Prio3Dev &P, const Workspace &W
 #ifndef WH_CHAIN_WAVES
 #define WH_CHAIN_WAVES 4
 #endif
+#ifndef WH_CHAIN_PRIO_MODE      // 0: no priorities outside the rotation runs; 1: rotating ranks; 2: fixed by chain length
+#define WH_CHAIN_PRIO_MODE 0
+#endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WH_CHAIN_WAVES, WH_CHAIN_WAVES)))
 k_chain(Prio3Dev P, Workspace W, uint32_t npad, uint64_t vk0, uint64_t vk1, const uint8_t *aes_rk, uint8_t *testing_ids,
         int32_t *status) {
-    chain_body<false>(P, W, npad, vk0, vk1, aes_rk, testing_ids, status);
+#if WH_CHAIN_PRIO_MODE == 2     // fixed by chain length: Helper chains 2, Leader chains 1, the short ones 0
+    const uint32_t seg = __builtin_amdgcn_readfirstlane(blockIdx.x * blockDim.x / npad);
+    if (seg == 0) chain_body<false, 2>(P, W, npad, vk0, vk1, aes_rk, testing_ids, status);
+    else if (seg == 1) chain_body<false, 1>(P, W, npad, vk0, vk1, aes_rk, testing_ids, status);
+    else chain_body<false, 0>(P, W, npad, vk0, vk1, aes_rk, testing_ids, status);
+#else
+    chain_body<false, WH_CHAIN_PRIO_MODE == 1 ? -1 : 0>(P, W, npad, vk0, vk1, aes_rk, testing_ids, status);
+#endif
 }
 // the same with the next rate block's loads in flight under the permutation (42 more VGPRs: three wavefronts a SIMD)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_chain_prefetch(Prio3Dev P, Workspace W, uint32_t npad, uint64_t vk0, uint64_t vk1, const uint8_t *aes_rk, uint8_t *testing_ids,
                  int32_t *status) {
-    chain_body<true>(P, W, npad, vk0, vk1, aes_rk, testing_ids, status);
+    chain_body<true, WH_CHAIN_PRIO_MODE == 1 ? -1 : 0>(P, W, npad, vk0, vk1, aes_rk, testing_ids, status);
 }
 
 void launch_chain(const Prio3Dev &P, const Workspace &W, uint32_t npad, bool prefetch, uint64_t vk0, uint64_t vk1,

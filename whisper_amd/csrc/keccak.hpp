@@ -184,6 +184,25 @@ WH_HD void keccak_f1600_ranked(uint64_t (&a)[25], uint32_t rank) {
 #endif
 }
 
+#if defined(__HIPCC__)
+// Equal shares of a SIMD's issue slots for long-lived sponge wavefronts.  A SIMD picks the oldest ready wavefront first: of
+// the sponge wavefronts it holds, two run at nearly full speed and the others get what is left.  A wavefront can instead
+// take its priority outside the rotation runs from the shader clock, which the wavefronts of a SIMD read alike: epochs of
+// 2^WH_PRIO_EPOCH_LOG2 cycles, rank = (wave slot + epoch) mod 3, so that over three epochs each has had every rank.
+#ifndef WH_PRIO_EPOCH_LOG2
+#define WH_PRIO_EPOCH_LOG2 21
+#endif
+__device__ __forceinline__ uint32_t wave_slot() { return __builtin_amdgcn_s_getreg((3 << 11) | 4); }   // HW_ID.wave_id
+__device__ __forceinline__ uint32_t rotate_prio(uint32_t slot) {
+#ifndef WH_MEAS_NO_ROTATE
+    const uint32_t epoch = (uint32_t)(__builtin_amdgcn_s_memtime() >> WH_PRIO_EPOCH_LOG2);
+    return __builtin_amdgcn_readfirstlane((slot + epoch) % 3);
+#else
+    return 0;
+#endif
+}
+#endif
+
 // unaligned little-endian loads/stores (byte-addressable on gfx950 and on x86)
 WH_HD uint64_t ld64(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 WH_HD F128 ld128(const uint8_t *p) { F128 v; __builtin_memcpy(&v, p, 16); return v; }
@@ -215,10 +234,22 @@ WH_HD void st128g(uint8_t *p, const F128 &v) { st128(p, v); }
 #endif
 
 // G: the byte streams this sponge absorbs and emits live in global memory (device kernels over reports and workspace rows)
-template <bool G>
+// PRIO (device): the wavefront's priority outside the rotation runs of the permutation -- 0..2 fixed, or -1: rotating
+// with the shader clock (rotate_prio; `slot` must hold wave_slot())
+template <bool G, int PRIO = 0>
 struct SpongeT {
     uint64_t st[25];
     uint32_t pos;  // bytes absorbed into (or squeezed from) the current rate block
+    uint32_t slot;
+
+    WH_HD void permute() {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (PRIO < 0) keccak_f1600_ranked(st, rotate_prio(slot));
+        else keccak_f1600_p<(PRIO < 0 ? 0 : PRIO)>(st);
+#else
+        keccak_f1600(st);
+#endif
+    }
 
     WH_HD void reset() {
 #pragma unroll
@@ -254,7 +285,7 @@ struct SpongeT {
 
     WH_HD void absorb_byte(uint8_t b) {
         xor_word(pos >> 3, (uint64_t)b << (8 * (pos & 7)));
-        if (++pos == SHAKE128_RATE) { keccak_f1600(st); pos = 0; }
+        if (++pos == SHAKE128_RATE) { permute(); pos = 0; }
     }
 
     // XofShake128::init (xof.rs:200-209): [len(dst)=8] || dst || seed, 25 bytes, written
@@ -282,7 +313,7 @@ struct SpongeT {
             xor_word(idx, w << sh);
             if (sh) xor_word(idx + 1, w >> (64 - sh));
             pos += 8;
-            if (pos == SHAKE128_RATE) { keccak_f1600(st); pos = 0; }
+            if (pos == SHAKE128_RATE) { permute(); pos = 0; }
         } else {
 #pragma unroll 1
             for (int i = 0; i < 8; i++) absorb_byte((uint8_t)(w >> (8 * i)));
@@ -307,7 +338,7 @@ struct SpongeT {
 #pragma unroll
                     for (int i = 0; i < (int)RATE_WORDS; i++) w[i] = G ? ld64g(p + 8 * i) : ld64(p + 8 * i);
                 }
-                keccak_f1600(st);
+                permute();
                 pos = 0;
                 if (pre) {
 #pragma unroll
@@ -343,7 +374,7 @@ struct SpongeT {
     WH_HD void finalize() {
         xor_word(pos >> 3, (uint64_t)0x1f << (8 * (pos & 7)));
         st[20] ^= 0x8000000000000000ULL;
-        keccak_f1600(st);
+        permute();
         pos = 0;
     }
     // Xof::into_seed (xof.rs:127-132): first 16 output bytes
@@ -356,8 +387,8 @@ typedef SpongeT<true> SpongeG;
 // stream, little endian, chunks >= p skipped; writes `n` elements (16 B each) at `out`.
 // Two rate blocks hold exactly 21 chunks, so the loop below is the whole stream walk.
 // `bound` is p everywhere except under the test hook wh_*_set_test_sampler_bound.
-template <bool G>
-WH_HD void xof_emit(SpongeT<G> &s, uint8_t *out, uint32_t n, const F128 &bound) {
+template <bool G, int PRIO>
+WH_HD void xof_emit(SpongeT<G, PRIO> &s, uint8_t *out, uint32_t n, const F128 &bound) {
     uint32_t left = n;
 #define WH_EMIT(lo_, hi_)                                                                      \
     do {                                                                                         \
@@ -370,12 +401,12 @@ WH_HD void xof_emit(SpongeT<G> &s, uint8_t *out, uint32_t n, const F128 &bound) 
         for (int i = 0; i < 10; i++) WH_EMIT(s.st[2 * i], s.st[2 * i + 1]);
         if (!left) break;
         uint64_t carry = s.st[20];
-        keccak_f1600(s.st);
+        s.permute();
         WH_EMIT(carry, s.st[0]);
 #pragma unroll
         for (int i = 0; i < 10; i++) WH_EMIT(s.st[2 * i + 1], s.st[2 * i + 2]);
         if (!left) break;
-        keccak_f1600(s.st);
+        s.permute();
     }
 #undef WH_EMIT
 }

@@ -858,7 +858,7 @@ template <bool BASE>
 __global__ void __launch_bounds__(256) k_query_polyeval(Prio3Dev P, Workspace W, uint8_t *tags,
                                                         uint8_t *out_shares, int32_t *status) {
     extern __shared__ F128 lds[];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t m = P.m, lg = P.log2m, calls = P.calls;
     // w^k, k < m / 2, for the butterflies: once per workgroup
     F128 *tw = lds + 4ull * m;
@@ -867,6 +867,7 @@ __global__ void __launch_bounds__(256) k_query_polyeval(Prio3Dev P, Workspace W,
     const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + wave;
     uint32_t i;
     if (!report_of_slot(W, slot, i)) return;
+    i = __builtin_amdgcn_readfirstlane(i);          // wave-uniform: what hangs off it comes through scalar loads
     uint8_t *tag_out = tags + 16ull * i;
     F128 *ver_row = reinterpret_cast<F128 *>(tags) + (uint64_t)i * P.ver_stride;   // BASE: verifier[3] (| joint-rand part)
     F128 *out_row = reinterpret_cast<F128 *>(out_shares) + (uint64_t)i;   // output_len == 1
@@ -1034,6 +1035,198 @@ __global__ void __launch_bounds__(256) k_query_polyeval(Prio3Dev P, Workspace W,
         if (bad) { status[i] = ST_ERR_MODULUS; tag = f_zero(); out = f_zero(); }
         out_row[0] = out;
         st128(tag_out, leader ? tag : f_neg(tag));
+    }
+}
+
+// ParallelSum circuits with at most QTINY_MAX_CALLS (two) gadget calls of at most 64 slots (Histogram of 128 with chunk 64: two
+// calls): the same Type::query + decide + RLC tag as k_query_psum (flp.rs:359-512, types.rs:410-437, 623-639,
+// prio3.rs:2703-2871), one WAVEFRONT per report.  k_query_psum streams a long share through a pipeline; for a share of a few
+// elements per lane that pipeline is a chain of ten dependent memory latencies around ~3 000 instructions (1.1 ms per 100 000
+// Histogram reports, 0.16 of the HBM rate).  Here every byte of the report a lane needs is requested before the first use --
+// the elements of its slot, its seeds, both public-proof pairs, its RLC coefficients, its gadget coefficient, the tables of
+// the chain kernel -- the six 64-lane sums share one reduce-scatter, and the last step's products sit in eight lanes.
+constexpr uint32_t QTINY_MAX_CALLS = 2;
+#ifdef WH_QTINY_WAVES
+#define WH_QTINY_ATTR __attribute__((amdgpu_waves_per_eu(WH_QTINY_WAVES, WH_QTINY_WAVES)))
+#else
+#define WH_QTINY_ATTR
+#endif
+template <bool HIST, bool BASE>
+__global__ void __launch_bounds__(256) WH_QTINY_ATTR k_query_psum_tiny(Prio3Dev P, Workspace W, uint8_t *tags, uint8_t *out_shares, int32_t *status) {
+    // the report index is wave-uniform: said so explicitly, everything that hangs off it (descriptor, tables, weight limbs,
+    // scalars) then comes through scalar loads into SGPRs instead of one VGPR copy per lane
+    const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + wave;
+    uint32_t i;
+    if (!report_of_slot(W, slot, i)) return;
+    i = __builtin_amdgcn_readfirstlane(i);
+    uint8_t *tag_out = tags + 16ull * i;
+    F128 *ver_row = reinterpret_cast<F128 *>(tags) + (uint64_t)i * P.ver_stride;            // BASE
+    F128 *out_row = reinterpret_cast<F128 *>(out_shares) + (uint64_t)i * P.output_len;
+    if (status[i] != ST_OK) {               // uniform over the wavefront
+        for (uint32_t e = lane; e < P.output_len; e += 64) out_row[e] = f_zero();
+        if (BASE) for (uint32_t e = lane; e < P.ver_stride; e += 64) ver_row[e] = f_zero();
+        else if (lane == 0) st128(tag_out, f_zero());
+        return;
+    }
+    const uint32_t chunk = P.chunk, calls = P.calls, arity = P.arity, vl = P.verifier_len;
+    const RepDesc d = W.desc[i];
+    const RepScal *sc = &W.scal[i];
+    const RepPow *pw = &W.pows[i];
+    const uint8_t *pp0 = d.tail + 40, *pp1 = pp0 + 16ull * vl;
+    const uint8_t *rlc = reinterpret_cast<const uint8_t *>(W.rlc + (uint64_t)i * (vl + 5));
+    const bool leader = d.role == 0;
+    const bool act = lane < chunk;
+    const uint32_t k = act ? lane : 0;
+    uint32_t bad = 0;
+
+    // ---- every load of the report ----
+    F128 x[QTINY_MAX_CALLS];
+    bool xok[QTINY_MAX_CALLS];
+#pragma unroll
+    for (uint32_t u = 0; u < QTINY_MAX_CALLS; u++) {
+        const uint32_t idx = u * chunk + k;
+        xok[u] = u < calls && act && idx < P.input_len;
+        x[u] = ld128g(d.meas + 16ull * (xok[u] ? idx : 0));
+        if (!xok[u]) x[u] = f_zero();
+    }
+    const F128 s_even = ld128g(d.proof2 + 16ull * (2 * k)), s_odd = ld128g(d.proof2 + 16ull * (2 * k + 1));
+    F128 q_even = f_zero(), q_odd = f_zero(), c_even = f_zero(), c_odd = f_zero(), a0 = f_zero(), b0 = f_zero();
+    F128 t_first = f_zero(), t_last = f_zero(), hs = f_zero(), t_rlc = f_zero();
+    uint32_t rd0 = 0, rd1 = 0;
+    const uint32_t te = lane & 7;
+    if (!BASE) {
+        q_even = ld128g(pp1 + 16ull * (1 + 2 * k)); q_odd = ld128g(pp1 + 16ull * (2 + 2 * k));
+        a0 = ld128g(pp0 + 16ull * (1 + 2 * k)); b0 = ld128g(pp0 + 16ull * (2 + 2 * k));
+        c_even = ld128g(rlc + 16ull * (1 + 2 * k)); c_odd = ld128g(rlc + 16ull * (2 + 2 * k));
+        // first and last element of a public proof: pp0's in lane te = 2 (its decide), pp1's elsewhere (decide in te = 3, the
+        // differences of v[0] and G(r) in te = 0, 1)
+        t_first = ld128g(te == 2 ? pp0 : pp1); t_last = ld128g((te == 2 ? pp0 : pp1) + 16ull * (1 + arity));
+        // the last step's coefficient of lane te: rlc[0], rlc[1 + arity], rlc[vl .. vl + 4]
+        t_rlc = ld128g(rlc + 16ull * (te == 0 ? 0 : (te == 1 ? 1 + arity : vl + (te < 7 ? te - 2 : 0))));
+        hs = sc->hash;
+        rd0 = sc->rand_diff[0]; rd1 = sc->rand_diff[1];
+    }
+    const uint8_t *G = d.proof2 + 16ull * arity;
+    const uint32_t ge = lane < P.gpoly_len ? lane : 0;
+    F128 gcoef = ld128g(G + 16ull * ge);
+    const F128 stab = P.s_tab[ge];
+    const F128 L0 = pw->L0, h_sumL = pw->h_sumL;
+    const F128 rho_a = pw->rho_lo[k & 7], rho_b = pw->rho_hi[k >> 3];
+    const F128 r_a = pw->r_lo[lane & 7], r_b = pw->r_hi[(lane >> 3) & 7];
+    F128 rho2 = f_zero();
+    if (HIST) rho2 = sc->jr[P.jr_len + 1];
+    const uint4 *wsrc = reinterpret_cast<const uint4 *>(W.wlimbs + (uint64_t)i * 12 * calls);
+    uint4 wq[QTINY_MAX_CALLS][3];
+#pragma unroll
+    for (uint32_t u = 0; u < QTINY_MAX_CALLS; u++)
+#pragma unroll
+        for (int q = 0; q < 3; q++) wq[u][q] = wsrc[3 * (u < calls ? u : 0) + q];
+    if (!BASE && leader)
+        for (uint32_t e = lane; e < P.proof_len; e += 64) {       // proof share of run 1: hashed, never evaluated, but it has to decode
+            const F128 v = ld128g(d.proof1 + 16ull * e);
+            bad |= !f_in_range(v.lo, v.hi);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- the two wire sums of this lane's slot (lazy columns), Histogram's element sum ----
+    Lazy cA, cB;
+    f_lazy_zero(cA);
+    f_lazy_zero(cB);
+    F128 sx_p = f_zero();
+#pragma unroll
+    for (uint32_t u = 0; u < QTINY_MAX_CALLS; u++) {
+        if (u < calls) {                        // uniform
+            bad |= !f_in_range(x[u].lo, x[u].hi);
+            uint32_t xl[5];
+            f_split26(x[u], xl);
+            const uint32_t wL[5] = {wq[u][0].x, wq[u][0].y, wq[u][0].z, wq[u][0].w, wq[u][1].x};
+            const uint32_t wM[5] = {wq[u][1].y, wq[u][1].z, wq[u][1].w, wq[u][2].x, wq[u][2].y};
+            f_lazy_mac(cA, xl, wM);
+            f_lazy_mac(cB, xl, wL);
+            if (HIST) sx_p = f_add(sx_p, x[u]);
+        }
+    }
+    const F128 A = f_lazy_reduce(cA), B = f_lazy_reduce(cB);
+    const F128 rk = f_mul(rho_a, rho_b);                                            // rho^(k + 1)
+    bad |= act && (!f_in_range(s_even.lo, s_even.hi) | !f_in_range(s_odd.lo, s_odd.hi));
+    F128 v_even = f_add(f_mul(L0, s_even), f_mul(rk, A));
+    F128 v_odd = f_sub(f_add(f_mul(L0, s_odd), B), h_sumL);
+    F128 tag_p = f_zero(), acc0_p = f_zero(), acc1_p = f_zero();
+    if (!BASE) {
+        bad |= act && (!f_in_range(q_even.lo, q_even.hi) | !f_in_range(q_odd.lo, q_odd.hi) | !f_in_range(a0.lo, a0.hi) | !f_in_range(b0.lo, b0.hi));
+        if (leader) { v_even = f_sub(v_even, q_even); v_odd = f_sub(v_odd, q_odd); }
+        const F128 t0 = f_add(f_mul(c_even, v_even), f_mul(c_odd, v_odd));
+        const F128 t1 = f_mul(a0, b0), t2 = f_mul(q_even, q_odd);                  // decide's sums (flp.rs:483-512)
+        if (act) { tag_p = t0; acc0_p = t1; acc1_p = t2; }
+    }
+    // gadget polynomial: G(r) and <s, G>, one coefficient per lane (gpoly_len <= 15)
+    bad |= lane < P.gpoly_len && !f_in_range(gcoef.lo, gcoef.hi);
+    if (lane >= P.gpoly_len) gcoef = f_zero();
+    const F128 g_p = f_mul(gcoef, f_mul(r_a, r_b)), v0_p = f_mul(gcoef, stab);
+    // ---- six sums in one reduce-scatter: the lanes 8 g .. 8 g + 7 end up with sum g ----
+    F128 red;
+    {
+        const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
+        const F128 z = f_zero();
+        // values 0..7: tag, sx, acc0, acc1 | G(r), v0, -, -
+        const F128 k0 = f_add(sel_f(h5, g_p, tag_p), shfl_xor_f(sel_f(h5, tag_p, g_p), 32));
+        const F128 k1 = f_add(sel_f(h5, v0_p, sx_p), shfl_xor_f(sel_f(h5, sx_p, v0_p), 32));
+        const F128 k2 = f_add(sel_f(h5, z, acc0_p), shfl_xor_f(sel_f(h5, acc0_p, z), 32));
+        const F128 k3 = f_add(sel_f(h5, z, acc1_p), shfl_xor_f(sel_f(h5, acc1_p, z), 32));
+        const F128 m0 = f_add(sel_f(h4, k2, k0), shfl_xor_f(sel_f(h4, k0, k2), 16));
+        const F128 m1 = f_add(sel_f(h4, k3, k1), shfl_xor_f(sel_f(h4, k1, k3), 16));
+        red = f_add(sel_f(h3, m1, m0), shfl_xor_f(sel_f(h3, m0, m1), 8));
+#pragma unroll
+        for (int msk = 4; msk >= 1; msk >>= 1) red = f_add(red, shfl_xor_f(red, msk));
+    }
+    // group g = 4 h5 + 2 h4 + h3: 0 tag, 1 sx, 2 acc0, 3 acc1, 4 G(r), 5 v0
+    const F128 tag_w = readlane_f(red, 0), sx = readlane_f(red, 8), acc0 = readlane_f(red, 16), acc1 = readlane_f(red, 24);
+    const F128 g_at_r = readlane_f(red, 32);
+    F128 v0 = readlane_f(red, 40);
+    if (HIST) v0 = f_add(f_mul(rho2, v0), f_mul(f_sqr(rho2), f_sub(sx, P.half)));   // types.rs:428-436
+    if (BASE) {
+        bad = wave_or(bad);
+        if (bad) {
+            for (uint32_t e = lane; e < P.output_len; e += 64) out_row[e] = f_zero();
+            for (uint32_t e = lane; e < P.ver_stride; e += 64) ver_row[e] = f_zero();
+            if (lane == 0) status[i] = ST_ERR_MODULUS;
+            return;
+        }
+        if (act) { ver_row[1 + 2 * k] = v_even; ver_row[2 + 2 * k] = v_odd; }
+        if (lane == 0) { ver_row[0] = v0; ver_row[1 + arity] = g_at_r; if (P.ver_stride > vl) ver_row[vl] = sc->own; }
+    } else {
+        // decide on the two public proofs (prio3.rs:2762-2786), differences, RLC (:2859-2871): lane te holds one term
+        if (te == 2 || te == 3) bad |= !f_in_range(t_first.lo, t_first.hi) | !f_in_range(t_last.lo, t_last.hi);
+        const bool ok = f_is_zero(t_first) && f_eq(te == 2 ? acc0 : acc1, t_last);
+        const F128 d0 = leader ? f_sub(v0, t_first) : v0, dg = leader ? f_sub(g_at_r, t_last) : g_at_r;
+        const F128 mb = te == 0 ? d0 : (te == 1 ? dg : (leader ? f_neg(hs) : hs));   // share of zero: Leader -H, Helper +H (:2844-2855)
+        F128 term = f_mul(t_rlc, mb);
+        if (te == 2 || te == 3) term = ok ? f_zero() : t_rlc;
+        if (te == 4) term = rd0 ? t_rlc : f_zero();
+        if (te == 5) term = rd1 ? t_rlc : f_zero();
+        if (te == 7) term = tag_w;
+#pragma unroll
+        for (int msk = 4; msk >= 1; msk >>= 1) term = f_add(term, shfl_xor_f(term, msk));
+        bad = wave_or(bad);
+        if (lane == 0) {
+            if (bad) { status[i] = ST_ERR_MODULUS; term = f_zero(); }
+            // prepare_encoded_key: the Helper-role tag is negated (main.rs:53-59)
+            st128(tag_out, leader ? term : f_neg(term));
+        }
+        if (bad) {
+            for (uint32_t e = lane; e < P.output_len; e += 64) out_row[e] = f_zero();
+            return;
+        }
+    }
+    // ---- out share: truncate (types.rs:641-648) / the elements themselves (:439-442) ----
+    if (HIST) {
+#pragma unroll
+        for (uint32_t u = 0; u < QTINY_MAX_CALLS; u++)
+            if (xok[u]) out_row[u * chunk + k] = x[u];
+    } else {
+        for (uint32_t e0 = 0; e0 < P.output_len; e0 += 64)
+            truncate_block(P, d.meas, out_row, e0, e0 + 64 < P.output_len ? e0 + 64 : P.output_len, lane);
     }
 }
 

@@ -38,26 +38,7 @@ __device__ __forceinline__ void xor_shifted(uint64_t &b, const W2 &cur, uint32_t
 
 enum : uint32_t { LANE_FULL = 0, LANE_SQUEEZE = 1, LANE_ABSORB = 2 };
 
-// Equal shares of a SIMD's issue slots.  A SIMD picks the oldest ready wavefront first: of the three sponge wavefronts it
-// holds, two run at nearly full speed and the third gets what is left, so the two finish early and the third then runs
-// its chain alone at the issue rate of a lone wavefront (measured with tools/meas_bench.hip: the three end after 17, 26
-// and 36 ms).  Each wavefront therefore takes its priority outside the rotation runs of the permutation (keccak.hpp:
-// keccak_f1600_ranked) from the shader clock, which the wavefronts of a SIMD read alike: epochs of 2^WH_PRIO_EPOCH_LOG2
-// cycles, rank = (wave slot + epoch) mod 3, so that at any time the three hold the three ranks and over three epochs each
-// has had every rank.
-#ifndef WH_PRIO_EPOCH_LOG2
-#define WH_PRIO_EPOCH_LOG2 21
-#endif
-__device__ __forceinline__ uint32_t wave_slot() { return __builtin_amdgcn_s_getreg((3 << 11) | 4); }   // HW_ID.wave_id
-__device__ __forceinline__ uint32_t rotate_prio(uint32_t slot) {
-#ifndef WH_MEAS_NO_ROTATE
-    const uint32_t epoch = (uint32_t)(__builtin_amdgcn_s_memtime() >> WH_PRIO_EPOCH_LOG2);
-    return __builtin_amdgcn_readfirstlane((slot + epoch) % 3);
-#else
-    return 0;
-#endif
-}
-
+// (wave_slot / rotate_prio: keccak.hpp)
 // one rate block as ten 16-byte loads and one 8-byte load (any alignment)
 __device__ __forceinline__ void load_block(uint64_t (&w)[RATE_WORDS], const uint8_t *p) {
 #pragma unroll
