@@ -78,8 +78,11 @@ def alg_bytes_per_report(s, role):
     query_rd = 16 * IL + 16 * PL + 32 * VL + 16 * (VL + 5) + 48 * C + 848 + 112 + (16 * PL if role == 0 else 0)
     query_wr = 16 * OL + 16
     expand = (64 + 32 * PL) if role == 1 else 0                              # the two proof shares of a Helper
+    # chain (short shares: every sponge of the report in one launch) = what expand + meas + hash move; a Helper also reads back
+    # the shares it has just written
+    chain = expand + meas + hash_rd + hash_wr + ((16 * IL + 32 * PL) if role == 1 else 0)
     return {"expand": expand, "meas": meas, "hash": hash_rd + hash_wr, "query": query_rd + query_wr, "parse": 64 + 56,
-            "aggregate": 16 * OL + 1}
+            "aggregate": 16 * OL + 1, "chain": chain, "sort": 16 * 6 + 32 + 32}
 
 
 def main():
@@ -93,12 +96,20 @@ def main():
     ap.add_argument("--tiled", dest="distinct", action="store_false",
                     help="--unique distinct clients sharded on the CPU and tiled, instead of every report from a distinct client sharded on the GPU")
     ap.add_argument("--in-flight", type=int, default=1, help="contexts the steps alternate between (batches in flight)")
-    ap.add_argument("--with-sort", action="store_true", help="also sort by testing id and build the keep mask from bad ids inside the step")
+    ap.add_argument("--no-sort", dest="with_sort", action="store_false",
+                    help="leave the sort by testing id, the gather of ids + tags and the keep mask from the group test's bad ids out of the step "
+                         "(the step is then prepare + masked aggregate with a ready-made mask)")
+    ap.add_argument("--with-sort", dest="with_sort", action="store_true", help="(default) the whole GPU side of the server step")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="default run only: skip the short lines for the other Prio3 configurations (config 1, Histogram, Average) under `extra`")
     ap.add_argument("--host-buffers", choices=("pageable", "pinned"), default=None,
                     help="time the host-buffer entry points instead (wh_prio3_prepare_batch + wh_prio3_aggregate): reports start in host "
                          "memory, tags / ids / status / aggregate end there; PCIe inclusive")
+    ap.add_argument("--data-rank", type=int, default=None,
+                    help="make the synthetic clients of this rank instead of the process's own (tests: a one-rank run over another rank's shard)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.set_defaults(with_sort=True)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -123,8 +134,36 @@ def main():
 
     if args.workload in HH_WORKLOADS:
         return bench_hh(args, rank, local_rank, world, dev, backend)
-    wl = WORKLOADS[args.workload]
-    n = args.reports_per_gpu or wl["reports_per_gpu"]
+    result = bench_prio3(args, args.workload, args.reports_per_gpu, args.steps, args.warmup, rank, local_rank, world, dev, backend,
+                         cpu=not args.no_cpu_baseline)
+    if (rank == 0 and world == 1 and not args.no_extra and not args.no_cpu_baseline and not args.host_buffers and args.workload == "sumvec_large"
+            and not args.reports_per_gpu):
+        # the other Prio3 configurations of BASELINE.json (config 1 = the reference's shipped JSON, config 2 = Histogram) and the
+        # servers' third aggregation function, each at its own per-GPU size: short lines, same step, same clock
+        result["extra"] = {}
+        for name in ("sumvec_cfg1", "histogram", "average"):
+            r = bench_prio3(args, name, 0, max(args.steps, 10), max(args.warmup, 2), rank, local_rank, world, dev, backend, cpu=False)
+            result["extra"][name] = {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
+                                     "steps": r["steps"], "warmup": r["warmup"], "workload": r["config"]["workload"],
+                                     "reports_per_gpu": r["config"]["reports_per_gpu"], "status_nonzero": r["config"]["status_nonzero"],
+                                     "sort_and_keep_mask_in_step": r["config"]["sort_and_keep_mask_in_step"],
+                                     "valu_frac": r["valu"]["frac"], "roofline": {k: r["roofline"].get(k) for k in ("bound", "kernel", "frac", "achieved", "peak", "unit")},
+                                     "kernels": {k: round(v["ms_per_step"], 4) for k, v in r["kernels"].items()}}
+    if rank == 0 and result is not None:
+        print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+def bench_prio3(args, workload, reports_per_gpu, steps, warmup, rank, local_rank, world, dev, backend, cpu=True):
+    """One Prio3 workload: make the clients, time `steps` steps, return rank 0's result line (None on other ranks)."""
+    if world > 1:
+        import torch.distributed as dist
+    wl = WORKLOADS[workload]
+    n = reports_per_gpu or wl["reports_per_gpu"]
     params = W.Prio3Params(wl["circuit"], wl["bits"], wl["length"], wl["chunk"])
     s = params.sizes
     K = max(1, min(args.unique, n // 2 if n >= 2 else 1))
@@ -135,7 +174,8 @@ def main():
     if args.distinct:
         # ---- synthetic clients: n DISTINCT clients sharded on this GPU (wh_client_shard_many_gpu, byte-identical to the CPU
         # client); this server sees the Leader share of even clients and the Helper share of odd ones
-        rng = np.random.default_rng(1000 + rank)
+        drank = rank if args.data_rank is None else args.data_rank
+        rng = np.random.default_rng(1000 + drank)
         if wl["circuit"] == W.SUMVEC:
             meas = rng.integers(0, 1 << wl["bits"], (n, wl["length"]), dtype=np.uint64)
         elif wl["circuit"] == W.HISTOGRAM:
@@ -148,7 +188,7 @@ def main():
         d_l = torch.empty(n * L, dtype=torch.uint8, device=dev)
         d_h = torch.empty(n * H, dtype=torch.uint8, device=dev)
         t_shard = time.time()
-        vdaf.shard_batched_many_dev(meas, nonces, rands, rank << 40, d_l.data_ptr(), d_h.data_ptr())
+        vdaf.shard_batched_many_dev(meas, nonces, rands, drank << 40, d_l.data_ptr(), d_h.data_ptr())
         t_shard = time.time() - t_shard
         del meas
         pairs = n // 2
@@ -251,14 +291,14 @@ def main():
         for ln in lanes:
             ln.vdaf.synchronize()
 
-    for i in range(max(args.warmup, len(lanes) if args.warmup else 0)):
+    for i in range(max(warmup, len(lanes) if warmup else 0)):
         step(i)
     barrier()
     for ln in lanes:
         ln.vdaf.set_profiling(True)
         ln.vdaf.kernel_times(reset=True)
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         step(i)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -272,23 +312,43 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     n_bad_status = int((d_status != 0).sum().item())
+    # the result of the last step: this GPU's masked aggregate, or the combined one on every rank
+    import hashlib
+    agg_bytes = (lanes[(steps - 1) % len(lanes)].total if world > 1 else lanes[(steps - 1) % len(lanes)].agg).cpu().numpy().tobytes()
+    # what leaves the GPU per step for the host's group test: the sorted ids and tags, 32 B per report -- timed on its own (it
+    # is PCIe, not part of `value`), pinned destination, on the context stream
+    d2h = None
+    if args.with_sort and rank == 0:
+        ln = lanes[0]
+        h_ids = torch.empty(16 * n, dtype=torch.uint8).pin_memory()
+        h_tags = torch.empty(16 * n, dtype=torch.uint8).pin_memory()
+        # on torch's own stream (the context is idle here): the pinned-memory allocator remembers the streams a block was
+        # used on, and the context's stream is gone by the time these tensors are freed
+        h_ids.copy_(ln.sids, non_blocking=True); h_tags.copy_(ln.stags, non_blocking=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            h_ids.copy_(ln.sids, non_blocking=True); h_tags.copy_(ln.stags, non_blocking=True)
+            torch.cuda.synchronize()
+        d2h = {"bytes_per_step": 32 * n, "ms_per_step": 1e3 * (time.perf_counter() - t1) / 5,
+               "note": "sorted testing ids + tags to pinned host memory for general_binary_split_test; outside the timed region and outside `value`"}
 
     # ---- per-kernel roofline numbers (rank 0), HIP events on the launch stream
     n_lead = (n + 1) // 2
     n_help = n // 2
     per = {k: n_lead * alg_bytes_per_report(s, 0)[k] + n_help * alg_bytes_per_report(s, 1)[k]
-           for k in ("parse", "expand", "meas", "hash", "query", "aggregate")}
+           for k in ("parse", "expand", "meas", "hash", "query", "aggregate", "chain", "sort")}
     kernels = {}
     for k, (ms, cnt) in ktimes.items():
         if cnt:
-            kernels[k] = {"ms_per_step": ms / args.steps, "launches_per_step": cnt / args.steps}
+            kernels[k] = {"ms_per_step": ms / steps, "launches_per_step": cnt / steps}
             if k == "expand":
                 kernels[k]["overlapped"] = "side stream, beside k_meas: the event time includes the wait for free wave slots; not part of the step's sum"
             if k == "hash" and not os.environ.get("WH_HASH_B_MAIN") and not os.environ.get("WH_NO_SIDE_STREAM"):
                 kernels[k]["note"] = ("job A (joint / query randomness, barycentric weights) only; job B (hash of the public parts, "
                                       "RLC coefficients, testing ids) runs on the side stream beside k_meas, untimed")
             if k in per and ms > 0:      # algorithmic bytes of the step over the kernel's time: its own HBM roofline figure
-                kernels[k]["alg_gb_per_s"] = per[k] / (ms / args.steps * 1e-3) / 1e9
+                kernels[k]["alg_gb_per_s"] = per[k] / (ms / steps * 1e-3) / 1e9
                 kernels[k]["hbm_frac"] = kernels[k]["alg_gb_per_s"] / HBM_PEAK_GBS
     # expand and hash have a launch on the side stream whose event time includes waiting for free slots
     dom = max((k for k in kernels if k in per and k not in ("expand",)), key=lambda k: kernels[k]["ms_per_step"])
@@ -302,7 +362,7 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pmc = json.load(f)
-        ent = pmc.get(args.workload)
+        ent = pmc.get(workload)
         if ent and ent["reports_per_gpu"] == n and ("k_" + dom) in ent["kernels"]:
             kk = ent["kernels"]["k_" + dom]
             traffic = (kk["fetch_bytes"] + kk["write_bytes"]) * (1.0 / launches if launches > 1 else 1.0)
@@ -324,14 +384,16 @@ def main():
     blk_ = lambda nbytes: -(-nbytes // 168)
     meas_perms = (n_lead + n_help) * blk_(42 + 16 * s.input_len + 1) + n_help * (blk_(16 * s.input_len) + 1)   # k_meas alone
     meas_ms = kernels["meas"]["ms_per_step"] if "meas" in kernels else None
+    if dom == "chain":                         # the one-launch form holds every sponge of the step
+        meas_perms, meas_ms = total_perms, kernels["chain"]["ms_per_step"]
 
     result = None
     if rank == 0:
-        value = world * n * args.steps / elapsed
+        value = world * n * steps / elapsed
         result = {
             "metric": "verified+aggregated client reports/sec (node), Prio3 " + {W.SUMVEC: "SumVec", W.HISTOGRAM: "Histogram", W.AVERAGE: "Average"}[wl["circuit"]],
-            "value": value, "unit": "reports/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "value": value, "unit": "reports/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u128 (Field128 mod p) + u64 (Keccak lanes)", "data": "synthetic",
             "config": {"workload": wl["desc"], "reports_per_gpu": n, "distinct_clients": n_distinct, "clients_made_on": "gpu (wh_client_shard_many_gpu)" if args.distinct else "cpu, tiled",
                        "leader_report_bytes": s.leader_report_len, "helper_report_bytes": s.helper_report_len,
@@ -339,27 +401,30 @@ def main():
                        "parallelism": f"reports sharded over {world} GPU(s); all-gather + mod-p reduce of partial aggregates",
                        "combine": ("none (one GPU)" if world == 1 else "wh_comm: the library's RCCL binding (wh_prio3_allgather_reduce_dev)" if wh_comm
                                    else f"torch.distributed all_gather ({backend}) + wh_f128_sum_rows_dev" + (f"; wh_comm unavailable: {wh_comm_why}" if wh_comm_why else "")),
-                       "status_nonzero": n_bad_status, "client_gen_s": round(t_gen, 2),
+                       "status_nonzero": n_bad_status, "aggregate_sha256": hashlib.sha256(agg_bytes).hexdigest(),
+                       "aggregate_hex": agg_bytes.hex() if len(agg_bytes) <= 4096 else None, "client_gen_s": round(t_gen, 2),
                        "gpu_shard_clients_per_s": round(n / t_shard) if t_shard else None},
             "roofline": roofline_obj(dom, kernels, meas_perms, meas_ms, achieved, traffic, traffic_src, avg_ms, bytes_per_launch, launches),
             "valu": {"keccak_f1600_per_step": total_perms,
-                     "keccak_f1600_per_s": total_perms * args.steps / elapsed,
+                     "keccak_f1600_per_s": total_perms * steps / elapsed,
                      "keccak_f1600_peak_per_s": KECCAK_PEAK,
                      "keccak_f1600_peak_measured_per_s": KECCAK_PEAK_MEASURED,
-                     "frac": total_perms * args.steps / elapsed / KECCAK_PEAK,
-                     "frac_of_measured": total_perms * args.steps / elapsed / KECCAK_PEAK_MEASURED,
+                     "frac": total_perms * steps / elapsed / KECCAK_PEAK,
+                     "frac_of_measured": total_perms * steps / elapsed / KECCAK_PEAK_MEASURED,
                      "note": "whole step (query and aggregation included) against the permutation-only peaks of the roofline object"},
             "kernels": kernels,
         }
-        if not args.no_cpu_baseline:
+        if d2h:
+            result["d2h_tags_ids"] = d2h
+        if cpu:
             result["cpu_baseline"] = cpu_baseline(wl, tile_reports, nthreads, args.cpu_seconds)
-        print(json.dumps(result))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
     for ln in lanes:
         ln.vdaf.close()
+    del d_blob, d_off, lanes
+    torch.cuda.empty_cache()
     return result
+
+
 
 
 def try_wh_comm(objs, dev, trial):
@@ -433,10 +498,10 @@ def roofline_obj(dom, kernels, meas_perms, meas_ms, hbm_achieved, traffic, traff
     HBM figure (algorithmic bytes, PMC traffic) is kept in `hbm`."""
     hbm = {"achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS, "traffic": traffic,
            "traffic_source": traffic_src, "alg_bytes_per_launch": bytes_per_launch}
-    if dom != "meas" or not meas_ms:
+    if dom not in ("meas", "chain") or not meas_ms:
         return dict(hbm, bound="hbm", kernel="k_" + dom, avg_launch_ms=avg_ms)
     ach = meas_perms / (meas_ms * 1e-3) / 1e9
-    return {"bound": "valu", "kernel": "k_meas", "achieved": ach, "peak": KECCAK_PEAK / 1e9, "unit": "G Keccak-f[1600]/s",
+    return {"bound": "valu", "kernel": "k_" + dom, "achieved": ach, "peak": KECCAK_PEAK / 1e9, "unit": "G Keccak-f[1600]/s",
             "frac": ach / (KECCAK_PEAK / 1e9), "traffic": traffic,
             "peak_derivation": f"24 rounds x 180 instructions x 2 cycles (two VALU issue slots per four cycles and SIMD, measured: "
                                f"tools/inst_rate_gen.py) = {KECCAK_ISSUE_CYCLES} cycles per wavefront-permutation; 1024 SIMDs x 64 lanes x {MAX_CLOCK_HZ / 1e9} GHz",
@@ -492,12 +557,10 @@ def bench_host_buffers(args, vdaf, params, n, d_blob, d_off, keep, world, rank):
                    "chunk_mb": int(os.environ.get("WH_HOST_CHUNK_MB", "2048")), "status_nonzero": int((status != 0).sum())},
         "pcie": {"h2d_gb_per_s": nbytes * args.steps / elapsed / 1e9, "note": "report bytes over the whole step time (verification of chunk k runs under the copy of chunk k + 1)"},
     }
-    if rank == 0:
-        print(json.dumps(result))
     vdaf.close()
     if args.host_buffers == "pinned":
         W.lib.wh_host_free(p)
-    return result
+    return result if rank == 0 else None
 
 
 def bench_hh(args, rank, local_rank, world, dev, backend):

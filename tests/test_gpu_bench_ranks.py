@@ -41,6 +41,33 @@ def test_bench_two_ranks_one_gpu_prio3():
     assert two["value"] > 0 and abs(two["value"] * two["ms_per_step"] * 1e-3 - 2 * 3000) < 1
     assert abs(one["value"] * one["ms_per_step"] * 1e-3 - 3000) < 1
     assert two["roofline"]["bound"] in ("valu", "hbm") and "cpu_baseline" not in two
+    assert "all_gather (gloo)" in two["config"]["combine"] and one["config"]["combine"] == "none (one GPU)"
+    assert two["config"]["sort_and_keep_mask_in_step"] is True
+
+
+def test_two_rank_combined_aggregate_is_the_sum_of_the_shards_aggregates():
+    """The bytes, not the rate: the aggregate the two-rank run ends with (all-gather of both partials + on-GPU mod-p sum) equals the
+    element-wise sum mod p of what two one-rank runs compute over rank 0's and rank 1's shard (Aggregatable::merge,
+    vdaf.rs:658-676; the reference's property run_vdaf_batched checks, vdaf.rs:889-897, is on the same sums)."""
+    P128 = 2**128 - 7 * 2**66 + 1
+    args = ["--workload", "histogram", "--reports-per-gpu", "3000"]
+    parts = [_run(1, args + ["--data-rank", str(r)])["config"]["aggregate_hex"] for r in (0, 1)]
+    two = _run(2, args)["config"]["aggregate_hex"]
+    assert parts[0] != parts[1] and len(two) == 2 * 16 * 128
+    dec = lambda h: [int.from_bytes(bytes.fromhex(h[32 * e:32 * e + 32]), "little") for e in range(len(h) // 32)]
+    a, b, t = dec(parts[0]), dec(parts[1]), dec(two)
+    assert all(x < P128 for x in t)
+    assert t == [(x + y) % P128 for x, y in zip(a, b)]
+    # 3 000 Histogram clients per shard, 3 of each dropped by the keep mask: the shares of the two ROLES cancel only across the
+    # two servers, so nothing more can be said about one server's sums -- except that a different shard gives different bytes
+
+
+def test_comm_probe_child_sequence_world_one():
+    """tools/wh_comm_probe.py is what bench.py --gpus N starts per rank before it trusts the library's RCCL binding: the same
+    child, world = 1 (its own unique id), must bind RCCL, run both collectives and exit 0 on a one-GPU box."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "wh_comm_probe.py"), "self", "0", "1", "0"], capture_output=True,
+                       text=True, timeout=200, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
 
 
 def test_bench_two_ranks_one_gpu_heavy_hitters():

@@ -97,13 +97,22 @@ def test_full_size_two_servers(name, cfg, n):
         else:
             want = [int(x) for x in np.bincount(meas[keep == 1, 0].astype(np.int64), minlength=ln)]
         assert total == want
-        # a sample against the oracle, both servers
-        sample = [0, 1, int(bad[0]), int(bad[0]) + 1, n - 2, n - 1]
-        for blob, off, tags, ids in ((blob_a, off_a, tags_a, ids_a), (blob_b, off_b, tags_b, ids_b)):
+        # a sample against the oracle, both servers: 2 048 seeded-random clients per view plus every tampered one, their
+        # neighbours and the batch's ends -- tags, testing ids and status; and for the view whose out shares the context
+        # still holds (Alice's second pass) the out shares of the same sample, byte for byte
+        srng = np.random.default_rng(4242)
+        sample = np.unique(np.concatenate([srng.choice(n, 2048, replace=False), bad, np.minimum(bad + 1, n - 1), [0, 1, n - 2, n - 1]])).astype(np.int64)
+        outs_a = vdaf.out_shares()[sample]
+        for view, (blob, off, tags, ids, st) in enumerate(((blob_a, off_a, tags_a, ids_a, st_a), (blob_b, off_b, tags_b, ids_b, st_b))):
             off_h = off.cpu().numpy()
-            for i in sample:
-                rep = blob[int(off_h[i]):int(off_h[i + 1])].cpu().numpy().tobytes()
-                rc, tag, tid, _ = O.prio3_prepare_encoded_key(op, VK, rep)
-                assert rc == 0 and tags[i].tobytes() == tag and ids[i].tobytes() == tid, i
+            reps = [blob[int(off_h[i]):int(off_h[i + 1])].cpu().numpy() for i in sample]
+            o_off = np.zeros(len(reps) + 1, np.uint64)
+            o_off[1:] = np.cumsum([len(r) for r in reps])
+            o_tags, o_ids, o_status, o_outs = O.prio3_prepare_batch(op, VK, np.concatenate(reps), o_off, nthreads=16)
+            assert np.array_equal(o_status, st[sample])
+            assert np.array_equal(o_tags, tags[sample]) and np.array_equal(o_ids, ids[sample])
+            if view == 0:
+                assert np.array_equal(np.asarray(o_outs).reshape(len(sample), -1), outs_a)
+            del reps
     finally:
         vdaf.close()

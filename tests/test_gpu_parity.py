@@ -79,7 +79,8 @@ def test_xof_expand_bit_exact(small_ctx, n_elems, binder):
         assert out[i].tobytes() == O.xof_expand(seeds[i].tobytes(), dst, binder, n_elems)
 
 
-def test_sampler_rejection_branch_with_lowered_bound(small_ctx):
+@pytest.mark.parametrize("path", ("default", "long_share"))
+def test_sampler_rejection_branch_with_lowered_bound(small_ctx, path):
     """prng.rs:73-99 skips chunks >= p; SHAKE output gets there with probability 2^-59.  With the test
     bound at ~p/3 two of three chunks are skipped, in the XOF unit and in every XOF of a whole batch
     (client generator, oracle and GPU all sample with the same bound)."""
@@ -89,6 +90,8 @@ def test_sampler_rejection_branch_with_lowered_bound(small_ctx):
     p = W.Prio3Params(W.SUMVEC, 16, 16, 8)
     op = O.params(W.SUMVEC, 16, 16, 8)
     vdaf = W.Prio3(p)
+    if path == "long_share":
+        vdaf.set_option("chain_max_input_len", 0)      # lane pairs in k_meas, every Helper on the dirty list, the general path
     try:
         O.set_test_sampler_bound(bound)
         small_ctx.set_test_sampler_bound(bound)
@@ -136,7 +139,21 @@ CASES = [
     ("average_64", (W.AVERAGE, 64, 0, 0), 20),                     # AVG_BITS, bin-utils/src/lib.rs:34
     ("average_8", (W.AVERAGE, 8, 0, 0), 6),
     ("average_3", (W.AVERAGE, 3, 0, 0), 6),                        # m = 4
+    ("average_100", (W.AVERAGE, 100, 0, 0), 6),                    # more than 64 calls: two terms per lane
+    ("sumvec_one_call", (W.SUMVEC, 8, 4, 32), 7),                  # one / two gadget calls of at most 64 slots: the one-wavefront
+    ("sumvec_two_calls_ragged", (W.SUMVEC, 5, 9, 30), 7),          # query kernel, SumVec's truncate included
+    ("histogram_two_calls_ragged", (W.HISTOGRAM, 0, 100, 64), 7),
 ]
+# Every shape runs twice: the way the library would run it (short shares: all sponges in one launch, chain.hip; few gadget
+# calls: the one-wavefront query kernel), and forced down the long-share pipeline (k_expand + k_meas lane pairs + k_hash +
+# k_query_psum) that the large configurations take.
+PATHS = ("default", "long_share")
+
+
+def force_path(vdaf, path):
+    if path == "long_share":
+        vdaf.set_option("chain_max_input_len", 0)
+        vdaf.set_option("query_tiny", 0)
 
 
 def oracle_batch(op, reports):
@@ -144,8 +161,9 @@ def oracle_batch(op, reports):
     return O.prio3_prepare_batch(op, VK, blob, offsets, nthreads=8)
 
 
+@pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("name,cfg,n", CASES, ids=[c[0] for c in CASES])
-def test_prepare_and_aggregate_match_oracle(name, cfg, n):
+def test_prepare_and_aggregate_match_oracle(name, cfg, n, path):
     circ, bits, ln, ch = cfg
     p = W.Prio3Params(circ, bits, ln, ch)
     op = O.params(circ, bits, ln, ch)
@@ -166,6 +184,7 @@ def test_prepare_and_aggregate_match_oracle(name, cfg, n):
     x = bytearray(alice[0]); x[49:65] = b"\x00" * 12 + b"\xff" * 4; a_err.append(bytes(x))   # top word all ones, < p
 
     vdaf = W.Prio3(p)
+    force_path(vdaf, path)
     try:
         for reports in (a_err, bob):
             tags, ids, status = vdaf.prepare_encoded_keys(VK, reports)
@@ -400,7 +419,7 @@ def test_prepare_matches_oracle_on_random_shapes():
     for _ in range(6):
         ln = int(rng.integers(2, 61))
         shapes.append((W.HISTOGRAM, 0, ln, int(rng.integers(1, ln + 3))))
-    for bits in (1, 7, 33, 64):
+    for bits in (1, 7, 33, 64, 65, 127):
         shapes.append((W.AVERAGE, bits, 0, 0))
     for k, (circ, bits, ln, ch) in enumerate(shapes):
         p = W.Prio3Params(circ, bits, ln, ch)
@@ -409,17 +428,20 @@ def test_prepare_matches_oracle_on_random_shapes():
         lr, hr, _ = make_reports(p, n, seed=500 + k, nthreads=2)
         keep = np.ones(n, np.uint8)
         keep[2] = 0
-        vdaf = W.Prio3(p)
-        try:
-            for reports in server_views(lr, hr, {2}):
-                tags, ids, status = vdaf.prepare_encoded_keys(VK, reports)
-                o_tags, o_ids, o_status, o_outs = oracle_batch(op, reports)
-                assert np.array_equal(status, o_status) and not status.any(), (circ, bits, ln, ch)
-                assert np.array_equal(tags, o_tags) and np.array_equal(ids, o_ids), (circ, bits, ln, ch)
-                assert np.array_equal(np.asarray(vdaf.out_shares()).reshape(n, -1), np.asarray(o_outs).reshape(n, -1)), (circ, bits, ln, ch)
-                assert np.array_equal(vdaf.aggregate(keep), O.prio3_aggregate(o_outs, p.sizes.output_len, keep)), (circ, bits, ln, ch)
-        finally:
-            vdaf.close()
+        views = server_views(lr, hr, {2})
+        want = [oracle_batch(op, reports) for reports in views]
+        for path in PATHS:
+            vdaf = W.Prio3(p)
+            force_path(vdaf, path)
+            try:
+                for reports, (o_tags, o_ids, o_status, o_outs) in zip(views, want):
+                    tags, ids, status = vdaf.prepare_encoded_keys(VK, reports)
+                    assert np.array_equal(status, o_status) and not status.any(), (circ, bits, ln, ch, path)
+                    assert np.array_equal(tags, o_tags) and np.array_equal(ids, o_ids), (circ, bits, ln, ch, path)
+                    assert np.array_equal(np.asarray(vdaf.out_shares()).reshape(n, -1), np.asarray(o_outs).reshape(n, -1)), (circ, bits, ln, ch, path)
+                    assert np.array_equal(vdaf.aggregate(keep), O.prio3_aggregate(o_outs, p.sizes.output_len, keep)), (circ, bits, ln, ch, path)
+            finally:
+                vdaf.close()
 
 
 @pytest.mark.parametrize("cfg", [(W.SUMVEC, 16, 16, 8), (W.SUMVEC, 3, 11, 7), (W.HISTOGRAM, 0, 11, 3), (W.AVERAGE, 9, 0, 0)],
