@@ -75,7 +75,9 @@ enum {
 int32_t wh_ctx_create(int32_t device_id, const wh_prio3_params *params, wh_ctx **out);
 void wh_ctx_destroy(wh_ctx *ctx);
 int32_t wh_prio3_sizes_of(const wh_prio3_params *params, wh_prio3_sizes *out);
-/* last HIP error text for this context (valid until the next call) */
+/* the context's last error text, copied into a buffer of the calling thread (valid until that thread's next wh_last_error).
+ * With several threads on one context it may be another thread's failure: bracket the failing call and this query with
+ * wh_ctx_lock / wh_ctx_unlock to get the text of your own. */
 const char *wh_last_error(const wh_ctx *ctx);
 /* the HIP stream (hipStream_t) the context launches on, for callers that time or order work */
 void *wh_ctx_stream(wh_ctx *ctx);
@@ -211,7 +213,10 @@ int32_t wh_ntt_f128_batch(wh_ctx *ctx, const uint8_t *in, uint64_t n_in, uint64_
  * Prio3::aggregate prio3.rs:2445-2456).  keep[n]: 1 = aggregate, 0 = skip (NULL = keep all).
  * Reports with non-zero status are never aggregated.  WH_ERR_STATE unless the context's last workspace
  * user was wh_prio3_prepare_batch[_dev] or wh_prio3_prepare_init_batch[_dev] (+ finish): wh_flp_query_batch and
- * wh_client_shard_many_gpu overwrite the out shares. */
+ * wh_client_shard_many_gpu overwrite the out shares.  After wh_prio3_prepare_init_batch[_dev] also WH_ERR_STATE until
+ * wh_prio3_prepare_finish_batch has decided the batch (prepare_next, prio3.rs:2396-2442): before it the statuses are
+ * prepare_init's and no report has been accepted.  (wh_prio3_out_shares stays available there: it is the prepare state's
+ * truncated measurement share, Prio3PrepareState, which the test vectors list per report.) */
 int32_t wh_prio3_aggregate_dev(wh_ctx *ctx, const uint8_t *d_keep, uint8_t *d_agg);
 int32_t wh_prio3_aggregate(wh_ctx *ctx, const uint8_t *keep, uint8_t *agg);
 /* replaces: AggregateShare::merge across partial aggregates (main.rs:327-335); with one process
@@ -326,8 +331,10 @@ int32_t wh_sort_by_testing_id_dev(wh_ctx *ctx, const uint8_t *d_ids, uint64_t n,
  * capture, tight serving loops, harnesses that forbid hipMalloc.  Same arguments, same results, asynchronous on the context
  * stream, but the sort's scratch (second permutation buffer + count table, 5.0 MiB) is a file-scope __device__ array that
  * every GPU the library runs on holds until the process ends, so the call never allocates or frees anything.
- * n <= WH_SORT_NOALLOC_MAX_N (2^20), larger batches: WH_ERR_PARAM.  All calls on one GPU share that array: calls that
- * overlap in time on the same GPU (two contexts, two threads) race; calls on one context stream are ordered and safe. */
+ * n <= WH_SORT_NOALLOC_MAX_N (2^20), larger batches: WH_ERR_PARAM.  All calls on one GPU share that array; the entry point
+ * orders them itself: each waits, on its own stream, for a per-device event the call before it recorded (created with the
+ * scratch address at the first wh_ctx_create on the device), so two contexts on one GPU take turns.  Work that touches the
+ * array by other means is not covered.  WH_ERR_STATE if the array's address could not be resolved on this device. */
 #define WH_SORT_NOALLOC_MAX_N (1u << 20)
 int32_t wh_sort_by_testing_id_noalloc_dev(wh_ctx *ctx, const uint8_t *d_ids, uint64_t n, uint32_t *d_order,
                                           const uint8_t *d_tags, uint32_t tag_bytes, uint8_t *d_sorted_ids,

@@ -49,9 +49,19 @@ def test_prepare_init_reproduces_draft07_vectors(name):
             for j, t in enumerate(preps):
                 assert prep[j].tobytes().hex() == t["prep_shares"][0][agg_id]
                 assert [outs[j][16 * e:16 * e + 16].tobytes().hex() for e in range(p.output_len)] == t["out_shares"][agg_id]
-            assert vdaf.aggregate(None).tobytes().hex() == v["agg_shares"][agg_id]
+            # nothing is aggregated before prepare_next has accepted the prepare message (prio3.rs:2396-2442)
+            with pytest.raises(W.WhError) as e:
+                vdaf.aggregate(None)
+            assert e.value.code == -102
             per_agg_prep.append(prep)
             per_agg_out.append(outs)
+        for agg_id in range(na):
+            keys = [W.Prio3.encode_vdaf_key(agg_id, bytes.fromhex(t["public_share"]), bytes.fromhex(t["input_shares"][agg_id]),
+                                            bytes.fromhex(t["nonce"])) for t in preps]
+            vdaf.prepare_init_encoded_keys(vk, keys)
+            _, status = vdaf.prepare_finish(per_agg_prep)
+            assert not status.any()
+            assert vdaf.aggregate(None).tobytes().hex() == v["agg_shares"][agg_id]
         # prepare_shares_to_prepare_message + prepare_next, with the last aggregator's state in the context
         msgs, status = vdaf.prepare_finish(per_agg_prep)
         assert not status.any()
@@ -217,3 +227,44 @@ def test_prepare_init_mutated_keys_differential_fuzz(cfg, na):
             assert n_ok
     finally:
         vdaf.close()
+
+
+def test_prepare_init_takes_any_batch_length_in_sub_batches():
+    """server-base-prio3's loop takes a Vec of any length (main.rs:41-61): a batch larger than the workspace runs in sub-batches,
+    the prepare state (out shares, joint-rand seeds) lives outside the workspace, and prepare_finish sees the whole batch.
+    Same prepare shares, out shares, prepare messages, status and aggregate as the same batch in one piece."""
+    circ, bits, ln, ch, na, n = W.SUMVEC, 8, 10, 9, 2, 200
+    p = W.Prio3Params(circ, bits, ln, ch, na)
+    op = O.params(circ, bits, ln, ch, na)
+    vk = bytes(det(b"vk-sub", 16))
+    shards = []
+    for i in range(n):
+        nonce = bytes(det(b"sn%d" % i, 16))
+        rand = bytes(det(b"sr%d" % i, O.prio3_rand_size(op)))
+        shards.append((nonce,) + tuple(O.prio3_shard(op, measurement_for(circ, bits, ln, i), nonce, rand)))
+    keys = [[W.Prio3.encode_vdaf_key(a, ps, ish[a], nonce) for nonce, ps, ish in shards] for a in range(na)]
+    keys[0][17] = keys[0][17][:-3]                                           # one malformed key, one tampered nonce
+    keys[1][150] = keys[1][150][:-1] + bytes([keys[1][150][-1] ^ 1])
+    results = []
+    for sub in (0, 64):
+        vdaf = W.Prio3(p)
+        if sub:
+            vdaf.set_option("max_subbatch", sub)                              # 200 keys: sub-batches of 64 + 64 + 64 + 8 ... (equalised: 4 x 50)
+        try:
+            preps = [vdaf.prepare_init_encoded_keys(vk, keys[a]) for a in range(na)]      # the context ends with aggregator na - 1's state
+            outs = vdaf.out_shares()
+            msgs, status = vdaf.prepare_finish([pr for pr, _ in preps])
+            results.append(([pr.copy() for pr, _ in preps], [st.copy() for _, st in preps], outs, msgs, status, vdaf.aggregate(None)))
+        finally:
+            vdaf.close()
+    one, split = results
+    for x, y in zip(one, split):
+        if isinstance(x, list):
+            assert all(np.array_equal(a, b) for a, b in zip(x, y))
+        else:
+            assert np.array_equal(x, y)
+    # key 17 did not decode at aggregator 0 (its prepare share is zeros, so aggregator 1's decide fails); key 150's nonce differs
+    assert one[1][0][17] == -2 and one[4][17] == -7 and one[4][150] in (-7, -8) and int((one[4] != 0).sum()) == 2
+    j = 33
+    rc, want_prep, want_out = O.prio3_prepare_init(op, vk, na - 1, shards[j][0], shards[j][1], shards[j][2][na - 1])
+    assert rc == 0 and split[0][na - 1][j].tobytes() == want_prep and split[2][j].tobytes() == want_out

@@ -158,3 +158,31 @@ def test_entry_points_reject_a_null_context_without_touching_a_gpu():
     assert lib.wh_keep_mask_dev(None, p, n, p, 1, p) == -1
     assert lib.wh_hh_eval_and_check_batch(None, p, p, 64, n, 9, p, p, p) == -1
     assert lib.wh_hh_aggregate(None, p, p) == -1
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """A host without RCCL (here: WH_RCCL_LIBRARY names a file that does not exist, so only that file is tried): the
+    communicator entry points return WH_ERR_UNSUPPORTED and wh_comm_why carries the loader's message -- bench.py's probe
+    ('does RCCL load in this process at all?') and its torch.distributed fallback depend on that return.  The loader's
+    message is read with ONE dlerror() call (a second call returns NULL; building a std::string from it crashed)."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys\n"
+        "import whisper_amd._lib as L\n"
+        "buf = (C.c_uint8 * 128)()\n"
+        "rc = L.lib.wh_comm_unique_id(buf)\n"
+        "why = L.lib.wh_comm_why().decode()\n"
+        "rc2 = L.lib.wh_comm_unique_id(buf)\n"
+        "print(rc, rc2, why)\n"
+        "sys.exit(0 if rc == -103 and rc2 == -103 and 'RCCL not found' in why and 'no_such_dir' in why else 1)\n")
+    env = dict(os.environ, WH_RCCL_LIBRARY="/no_such_dir/librccl.so.1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_context_knobs_are_settable_without_a_gpu_error_path():
+    """wh_ctx_set_option / wh_ctx_get_option reject a null context and an unknown option before anything else."""
+    import ctypes as C
+    v = C.c_uint64()
+    assert W.lib.wh_ctx_set_option(None, 0, 1) == -1 and W.lib.wh_ctx_get_option(None, 0, C.byref(v)) == -1

@@ -80,3 +80,26 @@ def test_noalloc_sort_limits_and_empty_input():
             other.close()
     finally:
         vdaf.close()
+
+
+def test_two_contexts_on_one_gpu_take_turns_on_the_scratch():
+    """Two contexts (two streams) on one GPU call the allocation-free sort back to back with nothing awaited in between: the entry
+    point orders them by its per-device event, so neither sort sees the other's permutation buffer or count table."""
+    dev = torch.device("cuda:0")
+    a = W.Prio3(W.Prio3Params(W.SUMVEC, 2, 5, 3))
+    b = W.Prio3(W.Prio3Params(W.HISTOGRAM, 0, 4, 2))
+    try:
+        jobs = []
+        for rnd, (ctx, n) in enumerate(((a, 400_000), (b, 350_000), (a, 90_000), (b, 400_000), (a, 1_000), (b, 777))):
+            ids, _ = make_ids(n, 40 + rnd, 16)
+            d_ids = torch.from_numpy(ids).to(dev)
+            d_order = torch.full((n,), -1, dtype=torch.int32, device=dev)
+            jobs.append((ctx, ids, d_ids, d_order))
+        torch.cuda.synchronize()
+        for ctx, ids, d_ids, d_order in jobs:               # enqueue everything first: the sorts of a and b overlap in time
+            ctx.sort_by_testing_id_noalloc_dev(d_ids.data_ptr(), ids.shape[0], d_order.data_ptr(), None, 0, None, None)
+        a.synchronize(); b.synchronize()
+        for _, ids, _, d_order in jobs:
+            assert np.array_equal(d_order.cpu().numpy().view(np.uint32), expected_order(ids)), ids.shape
+    finally:
+        a.close(); b.close()

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-end check on the GPU box: full GPU suite, smoke(), default bench line
+# round-end check on the GPU box: full GPU suite, smoke(), the default bench line (tools/validate.sh)
 O=gpurun_out; mkdir -p $O
 timeout -k 10 1000 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > $O/gpu_tests.log 2>&1 || { tail -40 $O/gpu_tests.log; exit 1; }
 tail -2 $O/gpu_tests.log

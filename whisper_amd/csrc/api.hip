@@ -93,6 +93,7 @@ struct wh_ctx {
     uint64_t out_cap = 0, n_last = 0;
     // which entry point produced the out shares the context holds: aggregate / out_shares / prepare_finish refuse anything else
     enum Producer { NONE = 0, PREPARE_BATCH, PREPARE_INIT, FLP_QUERY } producer = NONE;
+    bool init_finished = false;  // PREPARE_INIT: wh_prio3_prepare_finish_batch has decided the batch (prepare_next, prio3.rs:2396-2442)
     int32_t *d_status_last = nullptr;  // status of the last batch: always context-owned memory (d_status_keep or d_status_own)
     int32_t *d_status_keep = nullptr; uint64_t status_keep_cap = 0;   // copy of a caller-owned status array (the _dev entry points)
     int32_t *d_status_own = nullptr; uint64_t status_cap = 0;
@@ -103,6 +104,7 @@ struct wh_ctx {
     uint64_t *d_offsets = nullptr; uint64_t off_cap = 0;
     uint8_t *d_tags = nullptr, *d_ids = nullptr; uint64_t tags_cap = 0, ids_cap = 0;
     uint8_t *d_prep = nullptr; uint64_t prep_cap = 0;
+    F128 *d_jr_seeds = nullptr; uint64_t jr_seeds_cap = 0;   // prepare_init's joint-rand seed per report (prepare state)
     // optional per-kernel timing with HIP events on the context stream (wh_ctx_set_profiling)
     bool profiling = false;
     struct Ev { hipEvent_t a, b; int id; };
@@ -133,6 +135,7 @@ struct wh_ctx {
     uint8_t *d_tmp_b = nullptr; uint64_t tmp_b_cap = 0;
     uint8_t *d_tmp_c = nullptr; uint64_t tmp_c_cap = 0;
     uint32_t *d_scratch = nullptr;      // this device's copy of the file-scope `scratch` array (not owned)
+    std::string scratch_err;            // why d_scratch is empty, if it is
     // every entry point holds this while it works on the context, so threads may share a context; a caller that needs a
     // sequence of calls undisturbed (prepare ... aggregate) brackets it with wh_ctx_lock / wh_ctx_unlock (recursive)
     std::recursive_mutex mu;
@@ -162,6 +165,10 @@ namespace {
 constexpr int MAX_DEVICES = 64;
 std::mutex g_scratch_mu;
 uint32_t *g_scratch_ptr[MAX_DEVICES] = {nullptr};
+// "last user" of a device's scratch: every allocation-free sort waits for it on its own stream before it launches and records
+// it afterwards, so two contexts on one GPU (two streams) take their turns on the array instead of racing.  Created with the
+// address, once per device: the sort itself creates nothing.
+hipEvent_t g_scratch_ev[MAX_DEVICES] = {nullptr};
 int32_t scratch_of_device(wh_ctx *c) {
     if (c->device < 0 || c->device >= MAX_DEVICES) { c->err = "device index beyond the scratch table"; return WH_ERR_NO_DEVICE; }
     std::lock_guard<std::mutex> g(g_scratch_mu);
@@ -169,6 +176,9 @@ int32_t scratch_of_device(wh_ctx *c) {
         void *p = nullptr;
         HIPCHK(c, hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
         if (!p) { c->err = "hipGetSymbolAddress(scratch) returned a null address"; return WH_ERR_HIP; }
+        hipEvent_t ev = nullptr;
+        HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        g_scratch_ev[c->device] = ev;
         g_scratch_ptr[c->device] = static_cast<uint32_t *>(p);
     }
     c->d_scratch = g_scratch_ptr[c->device];
@@ -360,7 +370,9 @@ int32_t wh_ctx_create(int32_t device_id, const wh_prio3_params *params, wh_ctx *
             hipEventCreateWithFlags(&c->ev_done[b], hipEventDisableTiming) != hipSuccess) return fail(WH_ERR_HIP);
     c->err.reserve(256);                 // later error texts need no host allocation either
     knobs_from_env(c->knobs);            // the only look at the environment
-    if ((rc = scratch_of_device(c))) return fail(rc);
+    // the allocation-free sort's scratch: a context that never calls that entry point must not depend on it, so a failure
+    // here only leaves d_scratch empty (wh_sort_by_testing_id_noalloc_dev then reports WH_ERR_STATE with this text)
+    if (scratch_of_device(c) != WH_OK) { c->d_scratch = nullptr; c->scratch_err = c->err; c->err.clear(); }
 
     // constant tables: w^j and s_i = sum_{j=1..calls} w^(ij)
     std::vector<F128> omega(z.m), stab(z.gpoly_len);
@@ -402,7 +414,7 @@ void wh_ctx_destroy(wh_ctx *c) {
     if (c->stream2) hipStreamSynchronize(c->stream2);
     if (c->stream3) hipStreamSynchronize(c->stream3);
     void *ptrs[] = {c->d_omega, c->d_stab, c->d_aes, c->d_out_shares, c->d_status_own, c->d_status_keep, c->d_tmp_a, c->d_tmp_b, c->d_tmp_c, c->d_keep_eff, c->d_partials,
-                    c->d_blob, c->d_offsets, c->d_tags, c->d_ids, c->d_prep, c->W.desc, c->W.scal, c->W.weights, c->W.wlimbs, c->W.pows, c->W.rlc,
+                    c->d_blob, c->d_offsets, c->d_tags, c->d_ids, c->d_prep, c->d_jr_seeds, c->W.desc, c->W.scal, c->W.weights, c->W.wlimbs, c->W.pows, c->W.rlc,
                     c->W.hrows, c->W.hlist, c->W.llist, c->W.dirty, c->W.counters,
                     c->d_omega2m, c->d_twist, c->d_hh_tab, c->hh_w.tpc, c->hh_w.proofblk, c->hh_w.supd, c->hh_w.buckg, c->d_hh_dat, c->d_hh_keys, c->d_hh_tags,
                     c->d_hh_ids, c->d_hh_status, c->d_hh_keep, c->d_hh_acc, c->d_hh_part, c->d_sort_tmp, c->d_sort_hist, c->d_bad_ids};
@@ -423,7 +435,17 @@ void wh_ctx_destroy(wh_ctx *c) {
     delete c;
 }
 
-const char *wh_last_error(const wh_ctx *c) { return c ? c->err.c_str() : "null context"; }
+// The text is copied under the context's lock into a buffer of the CALLING thread: the pointer stays valid until that thread
+// asks again, whatever other threads do to the context meanwhile.  It is the context's last error: a thread that wants the
+// text of its own failed call brackets call and query with wh_ctx_lock / wh_ctx_unlock.
+const char *wh_last_error(const wh_ctx *c) {
+    if (!c) return "null context";
+    static thread_local std::string mine;
+    wh_ctx *m = const_cast<wh_ctx *>(c);
+    std::lock_guard<std::recursive_mutex> g(m->mu);
+    mine = m->err;
+    return mine.c_str();
+}
 // the funnel for concurrent callers (32 tokio tasks, a rayon pool): tasks queue on the context; recursive, so the calls
 // inside a bracket still take it
 int32_t wh_ctx_lock(wh_ctx *c) { if (!c) return WH_ERR_PARAM; c->mu.lock(); return WH_OK; }
@@ -567,45 +589,53 @@ int32_t wh_prio3_prepare_init_batch_dev(wh_ctx *c, const uint8_t verify_key[16],
     c->P.half = f_inv(f_small(c->params.num_aggregators));
     if ((rc = alloc_workspace(c, pick_cap(c, n)))) return rc;
     if ((rc = ensure(c, c->d_out_shares, c->out_cap, (n ? n : 1) * (uint64_t)z.output_len))) return rc;
-    if (n > c->cap) { c->err = "prepare_init keeps its state in the workspace: one sub-batch only"; return WH_ERR_UNSUPPORTED; }
+    // the prepare state prepare_finish needs (Prio3PrepareState, prio3.rs:1976-2010): the out shares above and the joint-rand
+    // seed of every report -- kept outside the workspace, so a batch may take any number of sub-batches, as the reference's
+    // loop takes any Vec (server-base-prio3/src/main.rs:41-61)
+    if ((rc = ensure(c, c->d_jr_seeds, c->jr_seeds_cap, n ? n : 1))) return rc;
     if (d_status != c->d_status_own && (rc = ensure(c, c->d_status_keep, c->status_keep_cap, n ? n : 1))) return rc;
     uint64_t vk0, vk1;
     memcpy(&vk0, verify_key, 8); memcpy(&vk1, verify_key + 8, 8);
-    c->producer = wh_ctx::NONE; c->n_last = 0;
+    c->producer = wh_ctx::NONE; c->n_last = 0; c->init_finished = false;
     const QueryLaunch q = query_launch(c, true);
     if (!q.fn) { c->err = "circuit has too many gadget calls for the query kernel's LDS rows"; return WH_ERR_UNSUPPORTED; }
-    if (!n) { c->d_status_last = nullptr; c->producer = wh_ctx::PREPARE_INIT; return WH_OK; }
-    const uint32_t nb = (uint32_t)n, npad = (nb + 255) / 256 * 256;
+    if (!n) { c->d_status_last = nullptr; c->producer = wh_ctx::PREPARE_INIT; c->init_finished = true; return WH_OK; }   // nothing to decide
     uint8_t *d_out = reinterpret_cast<uint8_t *>(c->d_out_shares);
-    HIPCHK(c, hipMemsetAsync(c->W.counters, 0, 64, c->stream));
-    { KTimer t_(c, WH_K_PARSE);
-    hipLaunchKernelGGL(k_parse_base, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, d_blob, d_offsets, nb, d_status,
-                       d_prep, d_out); }
-    // as in the batched path: the Helpers' proof shares on the side stream, the measurement shares and their joint-rand
-    // sponges in k_meas (Leader lanes absorb from the key, Helper lane pairs squeeze and absorb in step); keys whose share
-    // stream had a rejected chunk go through the general path.  WH_BASE_NO_MEAS keeps the two-pass form (expand, then absorb).
+    const uint64_t prep_row = 16ull * (z.verifier_len + 1);
     const bool paired = c->knobs.v[WH_OPT_BASE_PAIRED] != 0;
-    if (paired) {
-        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-        { KTimer t_(c, WH_K_EXPAND, c->stream2);
-        launch_expand(c->P, c->W, npad, 1, c->stream2); }
-        HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
-        { KTimer t_(c, WH_K_MEAS);
-        launch_meas(c->P, c->W, 0, npad, d_status, c->stream); }
-        launch_expand(c->P, c->W, npad, 2, c->stream);
-        launch_meas(c->P, c->W, 1, npad, d_status, c->stream);
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-    } else {
-        KTimer t_(c, WH_K_EXPAND);
-        launch_expand(c->P, c->W, npad, 0, c->stream);
+    for (uint64_t base = 0; base < n; base += c->cap) {
+        const uint32_t nb = (uint32_t)(n - base < c->cap ? n - base : c->cap), npad = (nb + 255) / 256 * 256;
+        uint8_t *prep_b = d_prep + prep_row * base, *out_b = d_out + 16 * base * z.output_len;
+        int32_t *status_b = d_status + base;
+        HIPCHK(c, hipMemsetAsync(c->W.counters, 0, 64, c->stream));
+        { KTimer t_(c, WH_K_PARSE);
+        hipLaunchKernelGGL(k_parse_base, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, d_blob, d_offsets + base, nb, status_b,
+                           prep_b, out_b); }
+        // as in the batched path: the Helpers' proof shares on the side stream, the measurement shares and their joint-rand
+        // sponges in k_meas (Leader lanes absorb from the key, Helper lane pairs squeeze and absorb in step); keys whose share
+        // stream had a rejected chunk go through the general path.  WH_OPT_BASE_PAIRED = 0 keeps the two-pass form.
+        if (paired) {
+            HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+            { KTimer t_(c, WH_K_EXPAND, c->stream2);
+            launch_expand(c->P, c->W, npad, 1, c->stream2); }
+            HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
+            { KTimer t_(c, WH_K_MEAS);
+            launch_meas(c->P, c->W, 0, npad, status_b, c->stream); }
+            launch_expand(c->P, c->W, npad, 2, c->stream);
+            launch_meas(c->P, c->W, 1, npad, status_b, c->stream);
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        } else {
+            KTimer t_(c, WH_K_EXPAND);
+            launch_expand(c->P, c->W, npad, 0, c->stream);
+        }
+        { KTimer t_(c, WH_K_HASH);
+        hipLaunchKernelGGL(k_hash_base, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, vk0, vk1, status_b, paired ? 1u : 0u); }
+        { KTimer t_(c, WH_K_QUERY);
+        hipLaunchKernelGGL(q.fn, query_grid(q, nb), dim3(64 * q.waves), q.lds, c->stream, c->P, c->W, prep_b, out_b, status_b); }
+        hipLaunchKernelGGL(k_keep_seeds, dim3(npad / 256), dim3(256), 0, c->stream, c->W, nb, c->d_jr_seeds + base);
+        HIPCHK(c, hipGetLastError());
     }
-    { KTimer t_(c, WH_K_HASH);
-    hipLaunchKernelGGL(k_hash_base, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, vk0, vk1, d_status, paired ? 1u : 0u); }
-    { KTimer t_(c, WH_K_QUERY);
-    hipLaunchKernelGGL(q.fn, query_grid(q, nb), dim3(64 * q.waves), q.lds, c->stream, c->P, c->W, d_prep,
-                       d_out, d_status); }
-    HIPCHK(c, hipGetLastError());
     if ((rc = remember_status(c, d_status, n))) return rc;
     c->n_last = n; c->producer = wh_ctx::PREPARE_INIT;
     return WH_OK;
@@ -616,7 +646,7 @@ int32_t wh_prio3_prepare_init_batch(wh_ctx *c, const uint8_t verify_key[16], con
     if (!c || !verify_key || (n && (!blob || !offsets || !prep_shares || !status))) return WH_ERR_PARAM;
     WH_LOCK(c);
     HIPCHK(c, hipSetDevice(c->device));
-    if (n == 0) { c->n_last = 0; c->d_status_last = nullptr; c->producer = wh_ctx::PREPARE_INIT; return WH_OK; }
+    if (n == 0) { c->n_last = 0; c->d_status_last = nullptr; c->producer = wh_ctx::PREPARE_INIT; c->init_finished = true; return WH_OK; }
     for (uint64_t i = 0; i < n; i++) if (offsets[i + 1] < offsets[i]) return WH_ERR_PARAM;
     int32_t rc;
     const uint64_t base0 = offsets[0], bytes = offsets[n] - base0, prep_bytes = 16ull * (c->z.verifier_len + 1) * n;
@@ -642,7 +672,7 @@ int32_t wh_prio3_prepare_finish_batch(wh_ctx *c, const uint8_t *const *prep_shar
     WH_LOCK(c);
     HIPCHK(c, hipSetDevice(c->device));
     if (c->producer != wh_ctx::PREPARE_INIT || n != c->n_last || (n && c->d_status_last != c->d_status_own)) return WH_ERR_STATE;
-    if (n == 0) return WH_OK;
+    if (n == 0) { c->init_finished = true; return WH_OK; }
     const uint32_t na = c->params.num_aggregators;
     const uint64_t prep_bytes = 16ull * (c->z.verifier_len + 1) * n;
     for (uint32_t a = 0; a < na; a++) if (!prep_shares[a]) return WH_ERR_PARAM;
@@ -661,12 +691,13 @@ int32_t wh_prio3_prepare_finish_batch(wh_ctx *c, const uint8_t *const *prep_shar
     HIPCHK(c, hipMemcpyAsync(d_ptrs, ptrs.data(), sizeof(uint8_t *) * na, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));          // `ptrs` is a local
     HIPCHK(c, hipMemsetAsync(d_msgs, 0, 16 * n, c->stream));
-    hipLaunchKernelGGL(k_finish_base, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, c->stream, c->P, c->W, d_ptrs, (uint32_t)n,
+    hipLaunchKernelGGL(k_finish_base, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, c->stream, c->P, c->d_jr_seeds, d_ptrs, (uint32_t)n,
                        d_msgs, c->d_status_own);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(prep_msgs, d_msgs, 16 * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(status, c->d_status_own, 4 * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->init_finished = true;
     return WH_OK;
 }
 
@@ -889,20 +920,26 @@ int32_t wh_sort_by_testing_id_dev(wh_ctx *c, const uint8_t *d_ids, uint64_t n, u
 // count table are this device's copy of the file-scope `scratch` array instead of context buffers that grow on demand.
 // No hipMalloc / hipFree / event creation on any path; nothing in the scratch has to start at zero (every word the kernels
 // read in a pass was written earlier in that pass), so calls of different sizes may follow each other.  All calls on one
-// GPU share the array: two that overlap in time (two contexts, two streams) race.
+// GPU share the array: calls through this entry point are ordered among themselves by a per-device event (each waits for
+// the one before on its own stream), whatever context or stream they come from.
 int32_t wh_sort_by_testing_id_noalloc_dev(wh_ctx *c, const uint8_t *d_ids, uint64_t n, uint32_t *d_order, const uint8_t *d_tags,
                                           uint32_t tag_bytes, uint8_t *d_sorted_ids, uint8_t *d_sorted_tags) {
     if (!c || (n && (!d_ids || !d_order))) return WH_ERR_PARAM;
     WH_LOCK(c);
     if (n > SORT_NOALLOC_MAX_N) { c->err = "allocation-free sort: more than 2^20 ids (use wh_sort_by_testing_id_dev)"; return WH_ERR_PARAM; }
     if (d_sorted_tags && (!d_tags || !tag_bytes || tag_bytes % 16)) return WH_ERR_PARAM;
-    if (!c->d_scratch) return WH_ERR_STATE;
+    if (!c->d_scratch) { c->err = "allocation-free sort: no scratch on this device: " + c->scratch_err; return WH_ERR_STATE; }
     if (!n) return WH_OK;
     HIPCHK(c, hipSetDevice(c->device));
     uint32_t *tmp = c->d_scratch, *hist = c->d_scratch + SORT_NOALLOC_MAX_N;
+    // one user of the device's array at a time, in the order the calls arrive: behind the last user's event, ahead of the next
+    std::lock_guard<std::mutex> g(g_scratch_mu);
+    hipEvent_t ev = g_scratch_ev[c->device];
+    HIPCHK(c, hipStreamWaitEvent(c->stream, ev, 0));
     int e = launch_sort_by_id(d_ids, (uint32_t)n, d_order, tmp, hist, c->stream);
     if (!e && d_sorted_ids) e = launch_sort_gather(d_ids, 16, d_order, (uint32_t)n, d_sorted_ids, c->stream);
     if (!e && d_sorted_tags) e = launch_sort_gather(d_tags, tag_bytes, d_order, (uint32_t)n, d_sorted_tags, c->stream);
+    HIPCHK(c, hipEventRecord(ev, c->stream));
     if (e) { c->err = "allocation-free sort: kernel launch failed"; return WH_ERR_HIP; }
     return WH_OK;
 }
@@ -1051,25 +1088,38 @@ int32_t wh_prio3_prepare_batch(wh_ctx *c, const uint8_t verify_key[16], const ui
     if (const uint64_t v = c->knobs.v[WH_OPT_HOST_COPY_THREADS]) threads = (unsigned)v;
     threads = threads < 1 ? 1 : (threads > 8 ? 8 : threads);
     bool used[2] = {false, false};
+    // after the first enqueue an error must not return while the copy stream may still read the caller's blob (pinned input)
+    // or the staging buffers, nor leave work queued behind a context that reports "no batch": drain, then return
+    auto drain = [&](int32_t code) {
+        (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamSynchronize(c->stream2); (void)hipStreamSynchronize(c->stream3);
+        return code;
+    };
+#define HIPCHK_DRAIN(call)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) { c->err = std::string(#call) + ": " + hipGetErrorString(e_); return drain(WH_ERR_HIP); } \
+    } while (0)
     for (uint64_t k = 0; k < nchunks; k++) {
         const uint64_t b = k % nbuf, lo = first[k], hi = first[k + 1], bytes = offsets[hi] - offsets[lo];
         // the pinned staging of this buffer was last read by the copy of chunk k - 2
-        if (used[b]) HIPCHK(c, hipEventSynchronize(c->ev_h2d[b]));
+        if (used[b]) HIPCHK_DRAIN(hipEventSynchronize(c->ev_h2d[b]));
         uint64_t *rel = h_off + b * off_stride;
         for (uint64_t i = lo; i <= hi; i++) rel[i - lo] = offsets[i] - offsets[lo];
         const uint8_t *src = blob + offsets[lo];
         if (!pinned_in) { parallel_copy(h_bytes + b * dev_stride, src, bytes, threads); src = h_bytes + b * dev_stride; }
         // the device buffer was last read by the verification of chunk k - 2
-        if (used[b]) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_done[b], 0));
-        HIPCHK(c, hipMemcpyAsync(c->d_blob + b * dev_stride, src, bytes, hipMemcpyHostToDevice, c->copy_stream));
-        HIPCHK(c, hipMemcpyAsync(c->d_offsets + b * off_stride, rel, (hi - lo + 1) * 8, hipMemcpyHostToDevice, c->copy_stream));
-        HIPCHK(c, hipEventRecord(c->ev_h2d[b], c->copy_stream));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_h2d[b], 0));
+        if (used[b]) HIPCHK_DRAIN(hipStreamWaitEvent(c->copy_stream, c->ev_done[b], 0));
+        HIPCHK_DRAIN(hipMemcpyAsync(c->d_blob + b * dev_stride, src, bytes, hipMemcpyHostToDevice, c->copy_stream));
+        HIPCHK_DRAIN(hipMemcpyAsync(c->d_offsets + b * off_stride, rel, (hi - lo + 1) * 8, hipMemcpyHostToDevice, c->copy_stream));
+        HIPCHK_DRAIN(hipEventRecord(c->ev_h2d[b], c->copy_stream));
+        HIPCHK_DRAIN(hipStreamWaitEvent(c->stream, c->ev_h2d[b], 0));
         if ((rc = prepare_range(c, pl, c->d_blob + b * dev_stride, c->d_offsets + b * off_stride, hi - lo, lo, c->d_tags, c->d_ids,
-                                c->d_status_own))) return rc;
-        HIPCHK(c, hipEventRecord(c->ev_done[b], c->stream));
+                                c->d_status_own))) return drain(rc);
+        HIPCHK_DRAIN(hipEventRecord(c->ev_done[b], c->stream));
         used[b] = true;
     }
+#undef HIPCHK_DRAIN
     if ((rc = prepare_end(c, c->d_status_own, n))) return rc;
     HIPCHK(c, hipMemcpyAsync(tags, c->d_tags, 16 * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(ids, c->d_ids, 16 * n, hipMemcpyDeviceToHost, c->stream));
@@ -1139,6 +1189,9 @@ int32_t wh_prio3_aggregate_dev(wh_ctx *c, const uint8_t *d_keep, uint8_t *d_agg)
     HIPCHK(c, hipSetDevice(c->device));
     // only a prepare call leaves something to aggregate (not Type::query, not the sharder, which reuse the workspace)
     if (c->producer != wh_ctx::PREPARE_BATCH && c->producer != wh_ctx::PREPARE_INIT) return WH_ERR_STATE;
+    // draft-07: out shares exist once prepare_next has accepted the prepare message; before wh_prio3_prepare_finish_batch the
+    // statuses are prepare_init's and nothing has been decided
+    if (c->producer == wh_ctx::PREPARE_INIT && !c->init_finished) { c->err = "aggregate: the prepare_init batch has not been through prepare_finish"; return WH_ERR_STATE; }
     const uint64_t n = c->n_last;
     int32_t rc;
     if (n) {
@@ -1154,6 +1207,7 @@ int32_t wh_prio3_aggregate(wh_ctx *c, const uint8_t *keep, uint8_t *agg) {
     WH_LOCK(c);
     HIPCHK(c, hipSetDevice(c->device));
     if (c->producer != wh_ctx::PREPARE_BATCH && c->producer != wh_ctx::PREPARE_INIT) return WH_ERR_STATE;
+    if (c->producer == wh_ctx::PREPARE_INIT && !c->init_finished) { c->err = "aggregate: the prepare_init batch has not been through prepare_finish"; return WH_ERR_STATE; }
     const uint64_t n = c->n_last, len = c->z.output_len;
     int32_t rc;
     if ((rc = ensure(c, c->d_tmp_a, c->tmp_a_cap, len * 16))) return rc;

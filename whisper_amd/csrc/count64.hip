@@ -45,6 +45,7 @@ struct Count64 {
     uint64_t *d_part = nullptr;                              // [2 * AGG_BLOCKS + 1]
     uint64_t n_last = 0;
     bool valid = false;
+    bool finished = false;      // prepare_finish has decided the batch: only then are there out shares to hand out or sum
     uint64_t bound = P64;                                    // sampler bound (test hook)
 };
 constexpr uint32_t AGG_BLOCKS = 256;
@@ -211,7 +212,7 @@ int32_t count_init_dev(wh_ctx *c, Count64 *S, uint32_t na, const uint8_t vk[16],
                        uint8_t *d_prep, int32_t *d_status) {
     int32_t rc;
     if ((rc = c_ensure(c, S->d_out, S->out_cap, n ? n : 1))) return rc;
-    S->valid = false; S->n_last = 0;
+    S->valid = false; S->finished = false; S->n_last = 0;
     uint64_t k0, k1;
     memcpy(&k0, vk, 8); memcpy(&k1, vk + 8, 8);
     if (n) {
@@ -260,7 +261,7 @@ int32_t wh_prio3_count_prepare_init_batch(wh_ctx *c, uint32_t num_aggregators, c
         C_HIPCHK(c, hipMemcpyAsync(status, S->d_status, 4 * n, hipMemcpyDeviceToHost, st));
     }
     C_HIPCHK(c, hipStreamSynchronize(st));
-    S->n_last = n; S->valid = true;
+    S->n_last = n; S->valid = true; S->finished = n == 0;      // an empty batch has nothing left to decide
     return WH_OK;
 }
 
@@ -269,7 +270,7 @@ int32_t wh_prio3_count_prepare_finish_batch(wh_ctx *c, uint32_t num_aggregators,
     std::lock_guard<std::recursive_mutex> lk(ctx_mutex(c));
     Count64 *S = state_of(c);
     if (!S->valid || S->n_last != n) { ctx_set_error(c, "wh_prio3_count_prepare_finish_batch: no prepare_init batch of this size in the context"); return WH_ERR_STATE; }
-    if (!n) return WH_OK;
+    if (!n) { S->finished = true; return WH_OK; }
     C_HIPCHK(c, hipSetDevice(ctx_device(c)));
     int32_t rc;
     if ((rc = c_ensure(c, S->d_peer, S->peer_cap, 32ull * n * num_aggregators))) return rc;
@@ -282,6 +283,7 @@ int32_t wh_prio3_count_prepare_finish_batch(wh_ctx *c, uint32_t num_aggregators,
     C_HIPCHK(c, hipGetLastError());
     C_HIPCHK(c, hipMemcpyAsync(status, S->d_status, 4 * n, hipMemcpyDeviceToHost, st));
     C_HIPCHK(c, hipStreamSynchronize(st));
+    S->finished = true;
     return WH_OK;
 }
 
@@ -289,7 +291,7 @@ int32_t wh_prio3_count_out_shares(wh_ctx *c, uint8_t *out_shares) {
     if (!c) return WH_ERR_PARAM;
     std::lock_guard<std::recursive_mutex> lk(ctx_mutex(c));
     Count64 *S = state_of(c);
-    if (!S->valid) { ctx_set_error(c, "wh_prio3_count_out_shares: no prepare_init batch in the context"); return WH_ERR_STATE; }
+    if (!S->valid || !S->finished) { ctx_set_error(c, "wh_prio3_count_out_shares: no batch that has been through prepare_init and prepare_finish"); return WH_ERR_STATE; }
     if (!S->n_last) return WH_OK;
     if (!out_shares) return WH_ERR_PARAM;
     C_HIPCHK(c, hipSetDevice(ctx_device(c)));
@@ -302,7 +304,7 @@ int32_t wh_prio3_count_aggregate(wh_ctx *c, const uint8_t *keep, uint8_t agg[8])
     if (!c || !agg) return WH_ERR_PARAM;
     std::lock_guard<std::recursive_mutex> lk(ctx_mutex(c));
     Count64 *S = state_of(c);
-    if (!S->valid) { ctx_set_error(c, "wh_prio3_count_aggregate: no prepare_init batch in the context"); return WH_ERR_STATE; }
+    if (!S->valid || !S->finished) { ctx_set_error(c, "wh_prio3_count_aggregate: no batch that has been through prepare_init and prepare_finish"); return WH_ERR_STATE; }
     C_HIPCHK(c, hipSetDevice(ctx_device(c)));
     hipStream_t st = ctx_stream(c);
     const uint64_t n = S->n_last;

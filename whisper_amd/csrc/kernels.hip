@@ -325,7 +325,12 @@ __global__ void __launch_bounds__(256) k_hash_base(Prio3Dev P, Workspace W, uint
 // aggregators' verifier shares, decide (flp.rs:483-512), derive the joint-rand seed from the
 // parts in the prepare shares and compare it with the one prepare_init used.  One wavefront per
 // report.  shares[a] points at aggregator a's n prepare shares ((verifier_len + 1) elements each).
-__global__ void __launch_bounds__(256) k_finish_base(Prio3Dev P, Workspace W, const uint8_t *const *shares, uint32_t n,
+// the joint-rand seeds of a sub-batch, out of the workspace (which the next sub-batch reuses) into the prepare state
+__global__ void k_keep_seeds(Workspace W, uint32_t nb, F128 *seeds) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nb) seeds[i] = W.scal[i].hash;
+}
+__global__ void __launch_bounds__(256) k_finish_base(Prio3Dev P, const F128 *jr_seeds, const uint8_t *const *shares, uint32_t n,
                                                      uint8_t *prep_msgs, int32_t *status) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t i = blockIdx.x * (blockDim.x >> 6) + wave;
@@ -365,7 +370,7 @@ __global__ void __launch_bounds__(256) k_finish_base(Prio3Dev P, Workspace W, co
         int32_t st = ST_OK;
         if (bad) st = ST_ERR_MODULUS;
         else if (!ok) st = ST_ERR_DECIDE;
-        else if (!f_eq(seed, W.scal[i].hash)) st = ST_ERR_JOINT_RAND;
+        else if (!f_eq(seed, jr_seeds[i])) st = ST_ERR_JOINT_RAND;
         status[i] = st;
     }
 }
