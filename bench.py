@@ -268,13 +268,15 @@ def bench_prio3(args, workload, reports_per_gpu, steps, warmup, rank, local_rank
 
     def step(i):
         ln = lanes[i % len(lanes)]
-        ln.vdaf.prepare_batch_dev(VK, d_blob.data_ptr(), d_off.data_ptr(), n, ln.tags.data_ptr(), ln.ids.data_ptr(), ln.status.data_ptr())
         if args.with_sort:
-            # the rest of the server's step that can live on the GPU: order for the group test, mask from its verdict
-            ln.vdaf.sort_by_testing_id_dev(ln.ids.data_ptr(), n, ln.order.data_ptr(), ln.tags.data_ptr(), 16, ln.sids.data_ptr(), ln.stags.data_ptr())
+            # the whole GPU side of run_vdaf_prepare (main.rs:75-118): verify, order for the group test (the sort runs beside the
+            # sponge kernels), mask from the group test's verdict, masked aggregate
+            ln.vdaf.prepare_sorted_batch_dev(VK, d_blob.data_ptr(), d_off.data_ptr(), n, ln.tags.data_ptr(), ln.ids.data_ptr(), ln.status.data_ptr(),
+                                             ln.order.data_ptr(), ln.sids.data_ptr(), ln.stags.data_ptr())
             ln.vdaf.keep_mask_dev(ln.ids.data_ptr(), n, bad_ids, ln.keep.data_ptr())
             ln.vdaf.aggregate_dev(ln.keep.data_ptr(), ln.agg.data_ptr())
         else:
+            ln.vdaf.prepare_batch_dev(VK, d_blob.data_ptr(), d_off.data_ptr(), n, ln.tags.data_ptr(), ln.ids.data_ptr(), ln.status.data_ptr())
             ln.vdaf.aggregate_dev(d_keep.data_ptr(), ln.agg.data_ptr())
         if wh_comm:
             # RCCL all-gather of the raw limbs on the context stream, then the on-GPU mod-p row sum, inside the library
@@ -342,6 +344,8 @@ def bench_prio3(args, workload, reports_per_gpu, steps, warmup, rank, local_rank
     for k, (ms, cnt) in ktimes.items():
         if cnt:
             kernels[k] = {"ms_per_step": ms / steps, "launches_per_step": cnt / steps}
+            if k == "sort" and args.with_sort:
+                kernels[k]["overlapped"] = "own stream, beside the sponge kernels (wh_prio3_prepare_sorted_batch_dev); not part of the step's sum"
             if k == "expand":
                 kernels[k]["overlapped"] = "side stream, beside k_meas: the event time includes the wait for free wave slots; not part of the step's sum"
             if k == "hash" and not os.environ.get("WH_HASH_B_MAIN") and not os.environ.get("WH_NO_SIDE_STREAM"):
@@ -351,7 +355,7 @@ def bench_prio3(args, workload, reports_per_gpu, steps, warmup, rank, local_rank
                 kernels[k]["alg_gb_per_s"] = per[k] / (ms / steps * 1e-3) / 1e9
                 kernels[k]["hbm_frac"] = kernels[k]["alg_gb_per_s"] / HBM_PEAK_GBS
     # expand and hash have a launch on the side stream whose event time includes waiting for free slots
-    dom = max((k for k in kernels if k in per and k not in ("expand",)), key=lambda k: kernels[k]["ms_per_step"])
+    dom = max((k for k in kernels if k in per and k not in ("expand", "sort")), key=lambda k: kernels[k]["ms_per_step"])
     launches = kernels[dom]["launches_per_step"]
     avg_ms = kernels[dom]["ms_per_step"] / launches
     bytes_per_launch = per[dom] / launches
@@ -576,15 +580,27 @@ def bench_hh(args, rank, local_rank, world, dev, backend):
     n = clients * reps                                   # key chains per step, repetition-major
     ln = hh.key_chain_len(depth)
     rng = np.random.default_rng(0x5748 + rank)
-    K = max(1, min(args.unique, n))
+    # every key chain of the step from a distinct client generator run (wh_hh_gen_key_chain on the host cores, a few seconds);
+    # --tiled makes --unique of them and repeats those instead (the round-1/2 lines: 128 key chains = 3.8 MB, an XCD's L2)
+    K = n if args.distinct else max(1, min(args.unique, n))
     t_gen = time.time()
     uniq = np.zeros((K, ln), np.uint8)
-    for i in range(K):
-        bk = np.where(rng.integers(0, 2, 258) == 1, 1, 0xffffffff).astype(np.uint32)
-        bk[257] = 1
-        uniq[i], _ = hh.gen_key_chain(depth, i, int(rng.integers(0, N)), bk, rng.integers(0, 256, 32, dtype=np.uint8).tobytes())
+    buckets = np.where(rng.integers(0, 2, (K, 258)) == 1, 1, 0xffffffff).astype(np.uint32)
+    buckets[:, 257] = 1
+    alphas = rng.integers(0, N, K)
+    seeds = rng.integers(0, 256, (K, 32), dtype=np.uint8)
+
+    def gen(lo, hi):
+        for i in range(lo, hi):
+            uniq[i], _ = hh.gen_key_chain(depth, i, int(alphas[i]), buckets[i], seeds[i].tobytes())
+    from concurrent.futures import ThreadPoolExecutor
+    nthreads = max(1, min(16, os.cpu_count() or 1))
+    step_k = (K + 4 * nthreads - 1) // (4 * nthreads)
+    with ThreadPoolExecutor(nthreads) as ex:                     # the generator is C code behind ctypes: the threads run side by side
+        list(ex.map(lambda lo: gen(lo, min(K, lo + step_k)), range(0, K, step_k)))
     t_gen = time.time() - t_gen
-    keys = uniq[np.arange(n) % K].copy()
+    keys = uniq if K == n else uniq[np.arange(n) % K].copy()
+    del uniq
     keys[:, :8] = ((rank << 40) + np.arange(n, dtype=np.uint64) % clients).view(np.uint8).reshape(n, 8)   # client ids
     h = hh.HeavyHitters(N, device=local_rank)
     ext = torch.cuda.ExternalStream(h.stream, device=dev)
@@ -688,7 +704,7 @@ def bench_hh(args, rank, local_rank, world, dev, backend):
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 (AES-128 state bytes) + u32 (counters mod 2^32)", "data": "synthetic",
             "config": {"workload": wl["desc"], "clients_per_gpu": clients, "repetitions": reps, "buckets": N,
-                       "key_chains_per_step_per_gpu": n, "key_chain_bytes": ln, "distinct_key_chains_tiled": K,
+                       "key_chains_per_step_per_gpu": n, "key_chain_bytes": ln, "distinct_key_chains": K, "key_chains_tiled": K != n,
                        "inputs": "resident in HBM", "status_nonzero": n_bad_status, "client_gen_s": round(t_gen, 2),
                        "parallelism": f"key chains sharded over {world} GPU(s); integer all-reduce of the sketches",
                        "combine": ("none (one GPU)" if world == 1 else "wh_comm: the library's RCCL binding (wh_hh_allreduce_u32_dev)" if wh_comm
@@ -698,8 +714,9 @@ def bench_hh(args, rank, local_rank, world, dev, backend):
                          "peak_derivation": "table AES: 176 ds_read_b32 per block at 32 lanes/clk/CU = 111.7 G blocks/s at 2.4 GHz; instruction "
                                             "issue (VALU and LDS instructions of a SIMD do not overlap) 119.7 G blocks/s; the lower binds",
                          "ms_per_step_all_launches": main_ms, "aes_blocks_per_step": main_blocks,
-                         "sketch_sum": ("wh_hh_eval_and_sketch_batch_dev: a sub-batch's bucket vectors in a context scratch, summed by k_hh_sum_u32 on a second "
-                                        "stream under the proof kernels; rejected key chains re-expanded and subtracted (atomic adds)") if fused
+                         "sketch_sum": ("wh_hh_eval_and_sketch_batch_dev: a sub-batch's bucket vectors are written to a context scratch and summed by "
+                                        "k_hh_sum_u32 on a second stream under the proof kernels (NOT fused into the expansion: atomics lost, profiles/"
+                                        "r2_hh_fused_atomics.txt); the few rejected key chains are re-expanded and subtracted with atomic adds") if fused
                                        else "materialised by the caller, then k_hh_sum_u32 per repetition",
                          "hbm": {"achieved": main_bytes / (main_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": main_bytes / (main_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -110,6 +110,15 @@ int32_t wh_ctx_unlock(wh_ctx *ctx);
 int32_t wh_prio3_prepare_batch_dev(wh_ctx *ctx, const uint8_t verify_key[16], const uint8_t *d_blob,
                                    const uint64_t *d_offsets, uint64_t n, uint8_t *d_tags,
                                    uint8_t *d_testing_ids, int32_t *d_status);
+/* replaces: run_vdaf_prepare up to the group test (server-batch-prio3/src/main.rs:75-94) = the map over prepare_encoded_key AND
+ * `tags_and_shares.sort_by(testing_id)`: wh_prio3_prepare_batch_dev followed by wh_sort_by_testing_id_dev (below) in one call,
+ * with the same outputs as the two calls -- d_order[n]: position k of the sorted batch holds report d_order[k] (stable);
+ * d_sorted_ids[n][16], d_sorted_tags[n][16] (either may be NULL) in that order, ready for general_binary_split_test.  The
+ * testing ids exist once the batch is parsed, so the sort of the permutation runs on a side stream beside the sponge kernels
+ * and costs the step nothing; only the gather of the sorted tags waits for the tags.  n <= 2^28. */
+int32_t wh_prio3_prepare_sorted_batch_dev(wh_ctx *ctx, const uint8_t verify_key[16], const uint8_t *d_blob,
+                                          const uint64_t *d_offsets, uint64_t n, uint8_t *d_tags, uint8_t *d_testing_ids,
+                                          int32_t *d_status, uint32_t *d_order, uint8_t *d_sorted_ids, uint8_t *d_sorted_tags);
 /* Same with HOST buffers (what a Rust caller holding Vec<Vec<u8>> would use); copies in and out
  * and synchronises.  The batch crosses PCIe in chunks (2 GiB; WH_HOST_CHUNK_MB) through two device buffers, the copy of
  * chunk k+1 under the verification of chunk k.  Pageable input is staged through pinned context memory by several host

@@ -75,6 +75,7 @@ extern "C" {
     pub fn wh_ctx_lock(ctx: *mut WhCtx) -> i32;
     pub fn wh_ctx_unlock(ctx: *mut WhCtx) -> i32;
     pub fn wh_prio3_prepare_batch_dev(ctx: *mut WhCtx, verify_key: *const u8, d_blob: *const u8, d_offsets: *const u64, n: u64, d_tags: *mut u8, d_testing_ids: *mut u8, d_status: *mut i32) -> i32;
+    pub fn wh_prio3_prepare_sorted_batch_dev(ctx: *mut WhCtx, verify_key: *const u8, d_blob: *const u8, d_offsets: *const u64, n: u64, d_tags: *mut u8, d_testing_ids: *mut u8, d_status: *mut i32, d_order: *mut u32, d_sorted_ids: *mut u8, d_sorted_tags: *mut u8) -> i32;
     pub fn wh_prio3_prepare_batch(ctx: *mut WhCtx, verify_key: *const u8, blob: *const u8, offsets: *const u64, n: u64, tags: *mut u8, testing_ids: *mut u8, status: *mut i32) -> i32;
     pub fn wh_host_alloc(bytes: u64, out: *mut *mut c_void) -> i32;
     pub fn wh_host_free(p: *mut c_void) -> i32;

@@ -155,3 +155,59 @@ def test_device_resident_server_flow():
         assert W.Prio3.unshard(aggs) == [int(sum(int(meas[i][e]) for i in range(n) if i not in bad)) for e in range(16)]
     finally:
         vdaf.close()
+
+
+@pytest.mark.parametrize("cfg,path,sub", [((W.HISTOGRAM, 0, 128, 64), "default", 0), ((W.SUMVEC, 16, 16, 8), "default", 64),
+                                          ((W.SUMVEC, 16, 16, 8), "long_share", 64), ((W.AVERAGE, 9, 0, 0), "default", 0)],
+                         ids=["histogram", "sumvec_subbatches", "sumvec_long_share_path", "average"])
+def test_prepare_sorted_batch_equals_prepare_then_sort(cfg, path, sub):
+    """wh_prio3_prepare_sorted_batch_dev (the sort runs on its own stream beside the sponge kernels) against
+    wh_prio3_prepare_batch_dev followed by wh_sort_by_testing_id_dev: tags, ids, status, permutation, sorted ids and sorted tags
+    bit for bit -- with malformed reports (zero ids: ties that must keep their input order), several sub-batches, both pipelines,
+    and twice in a row on one context."""
+    import torch
+    from common import VK, blob_of, make_reports, server_views
+    p = W.Prio3Params(*cfg)
+    n = 300
+    lr, hr, _ = make_reports(p, n, seed=31, nthreads=4)
+    alice, _ = server_views(lr, hr, {5})
+    alice = list(alice)
+    for i in (7, 100, 101, 250):
+        alice[i] = alice[i][:20]                                              # undecodable: testing id 0
+    blob, off = blob_of(alice)
+    dev = torch.device("cuda:0")
+    d_blob = torch.from_numpy(np.concatenate([blob, np.zeros(1, np.uint8)])).to(dev)
+    d_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+
+    def bufs():
+        return dict(tags=torch.zeros(16 * n, dtype=torch.uint8, device=dev), ids=torch.full((16 * n,), 7, dtype=torch.uint8, device=dev),
+                    status=torch.full((n,), -99, dtype=torch.int32, device=dev), order=torch.full((n,), -1, dtype=torch.int32, device=dev),
+                    sids=torch.zeros(16 * n, dtype=torch.uint8, device=dev), stags=torch.zeros(16 * n, dtype=torch.uint8, device=dev))
+    vdaf = W.Prio3(p)
+    if path == "long_share":
+        vdaf.set_option("chain_max_input_len", 0)
+    if sub:
+        vdaf.set_option("max_subbatch", sub)
+    try:
+        a = bufs()
+        vdaf.prepare_batch_dev(VK, d_blob.data_ptr(), d_off.data_ptr(), n, a["tags"].data_ptr(), a["ids"].data_ptr(), a["status"].data_ptr())
+        vdaf.sort_by_testing_id_dev(a["ids"].data_ptr(), n, a["order"].data_ptr(), a["tags"].data_ptr(), 16, a["sids"].data_ptr(), a["stags"].data_ptr())
+        vdaf.synchronize()
+        agg_a = vdaf.aggregate(None)
+        for _ in range(2):
+            b = bufs()
+            vdaf.prepare_sorted_batch_dev(VK, d_blob.data_ptr(), d_off.data_ptr(), n, b["tags"].data_ptr(), b["ids"].data_ptr(), b["status"].data_ptr(),
+                                          b["order"].data_ptr(), b["sids"].data_ptr(), b["stags"].data_ptr())
+            vdaf.synchronize()
+            for k in a:
+                assert torch.equal(a[k], b[k]), k
+            assert np.array_equal(vdaf.aggregate(None), agg_a)
+        st = a["status"].cpu().numpy()
+        assert list(np.flatnonzero(st)) == [7, 100, 101, 250]
+        order = a["order"].cpu().numpy()
+        assert list(order[:4]) == [7, 100, 101, 250]                       # the zero ids first, in input order
+        ids = a["ids"].cpu().numpy().reshape(n, 16)
+        v = ids.view(np.uint64).reshape(n, 2)
+        assert np.array_equal(order.astype(np.int64), np.lexsort((np.arange(n), v[:, 0], v[:, 1])))
+    finally:
+        vdaf.close()

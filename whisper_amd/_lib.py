@@ -47,7 +47,7 @@ EXPORTS = [
     "wh_prio3_allgather_reduce_dev", "wh_f128_allgather_reduce_dev", "wh_prio3_allgather_reduce", "wh_hh_allreduce_u32_dev",
     "wh_prio3_count_prepare_init_batch", "wh_prio3_count_prepare_finish_batch", "wh_prio3_count_out_shares", "wh_prio3_count_aggregate",
     "wh_test_f64_xof_expand", "wh_prio3_count_set_test_sampler_bound",
-    "wh_ctx_set_option", "wh_ctx_get_option", "wh_comm_why",
+    "wh_ctx_set_option", "wh_ctx_get_option", "wh_comm_why", "wh_prio3_prepare_sorted_batch_dev",
 ]
 
 vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32
@@ -124,6 +124,7 @@ lib.wh_hh_buckets.argtypes = [vp, vp]
 lib.wh_hh_aggregate.argtypes = [vp, vp, vp]
 lib.wh_hh_aggregate_dev.argtypes = [vp, vp, vp, i32]
 lib.wh_hh_gen_key_chain.argtypes = [u32, vp, u32, vp, vp, vp, vp]
+lib.wh_prio3_prepare_sorted_batch_dev.argtypes = [vp, vp, vp, vp, u64, vp, vp, vp, vp, vp, vp]
 lib.wh_ctx_set_option.argtypes = [vp, i32, u64]
 lib.wh_ctx_get_option.argtypes = [vp, i32, C.POINTER(u64)]
 lib.wh_comm_why.argtypes = []

@@ -31,8 +31,8 @@ static __device__ __align__(256) uint32_t scratch[SORT_NOALLOC_MAX_N + SORT_NOAL
 namespace wh {
 void launch_expand(const Prio3Dev &P, const Workspace &W, uint32_t npad, uint32_t sel, hipStream_t stream);
 void launch_meas(const Prio3Dev &P, const Workspace &W, uint32_t mode, uint32_t npad, int32_t *status, hipStream_t stream);
-void launch_chain(const Prio3Dev &P, const Workspace &W, uint32_t npad, bool prefetch, uint64_t vk0, uint64_t vk1,
-                  const uint8_t *aes_rk, uint8_t *testing_ids, int32_t *status, hipStream_t stream);
+void launch_chain(const Prio3Dev &P, const Workspace &W, uint32_t npad, bool prefetch, uint64_t vk0, uint64_t vk1, int32_t *status,
+                  hipStream_t stream);
 }
 
 // Tuning and test knobs of a context (wh_ctx_set_option).  The environment variables of the same purpose are read ONCE, in
@@ -75,6 +75,9 @@ struct wh_ctx {
     // expansion, public-parts hash / RLC / testing id): they slip in beside k_meas
     hipStream_t stream2 = nullptr, stream3 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
+    // the sort by testing id beside the sponge kernels (wh_prio3_prepare_sorted_batch_dev)
+    hipStream_t stream_sort = nullptr;
+    hipEvent_t ev_ids = nullptr, ev_sorted = nullptr;
     // host-buffer entry points: copy stream, "chunk b has arrived" / "chunk b has been verified" events, pinned staging
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
@@ -365,6 +368,9 @@ int32_t wh_ctx_create(int32_t device_id, const wh_prio3_params *params, wh_ctx *
     if (hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) return fail(WH_ERR_HIP);
     if (hipEventCreateWithFlags(&c->ev_bad, hipEventDisableTiming) != hipSuccess) return fail(WH_ERR_HIP);
     if (hipStreamCreate(&c->copy_stream) != hipSuccess) return fail(WH_ERR_HIP);
+    if (hipStreamCreate(&c->stream_sort) != hipSuccess) return fail(WH_ERR_HIP);
+    if (hipEventCreateWithFlags(&c->ev_ids, hipEventDisableTiming) != hipSuccess) return fail(WH_ERR_HIP);
+    if (hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming) != hipSuccess) return fail(WH_ERR_HIP);
     for (int b = 0; b < 2; b++)
         if (hipEventCreateWithFlags(&c->ev_h2d[b], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_done[b], hipEventDisableTiming) != hipSuccess) return fail(WH_ERR_HIP);
@@ -413,6 +419,9 @@ void wh_ctx_destroy(wh_ctx *c) {
     wh::grouptest_free(c->grouptest); c->grouptest = nullptr;
     if (c->stream2) hipStreamSynchronize(c->stream2);
     if (c->stream3) hipStreamSynchronize(c->stream3);
+    if (c->stream_sort) { hipStreamSynchronize(c->stream_sort); hipStreamDestroy(c->stream_sort); }
+    if (c->ev_ids) hipEventDestroy(c->ev_ids);
+    if (c->ev_sorted) hipEventDestroy(c->ev_sorted);
     void *ptrs[] = {c->d_omega, c->d_stab, c->d_aes, c->d_out_shares, c->d_status_own, c->d_status_keep, c->d_tmp_a, c->d_tmp_b, c->d_tmp_c, c->d_keep_eff, c->d_partials,
                     c->d_blob, c->d_offsets, c->d_tags, c->d_ids, c->d_prep, c->d_jr_seeds, c->W.desc, c->W.scal, c->W.weights, c->W.wlimbs, c->W.pows, c->W.rlc,
                     c->W.hrows, c->W.hlist, c->W.llist, c->W.dirty, c->W.counters,
@@ -461,7 +470,8 @@ int32_t wh_ctx_synchronize(wh_ctx *c) {
 // One batched verification in two parts, so that the host-buffer entry point can feed it chunk by chunk while the next chunk
 // is still crossing PCIe: prepare_begin sizes the context for n reports (all allocations happen here), prepare_range enqueues
 // the kernel sequence for reports [base, base + nb) whose encodings sit at d_blob + d_off[0 .. nb].
-struct PrepPlan { uint64_t vk0 = 0, vk1 = 0; QueryLaunch q{}; };
+struct SortPlan { uint64_t n; uint32_t *d_order; uint8_t *d_sorted_ids; };
+struct PrepPlan { uint64_t vk0 = 0, vk1 = 0; QueryLaunch q{}; const SortPlan *sort = nullptr; };
 
 static int32_t prepare_begin(wh_ctx *c, const uint8_t verify_key[16], uint64_t n, uint64_t max_range, const int32_t *d_status,
                              PrepPlan &pl) {
@@ -504,12 +514,30 @@ static int32_t prepare_range(wh_ctx *c, const PrepPlan &pl, const uint8_t *d_blo
         HIPCHK(c, hipMemsetAsync(c->W.counters, 0, 64, c->stream));
         { KTimer t_(c, WH_K_PARSE);
         hipLaunchKernelGGL(k_parse, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, d_blob, d_off + r, nb,
-                           d_status + base, tags_b, d_ids + 16 * base, out_b); }
-        if (z.input_len <= c->knobs.v[WH_OPT_CHAIN_MAX_INPUT_LEN]) {
+                           d_status + base, tags_b, d_ids + 16 * base, out_b, c->d_aes); }
+        // wh_prio3_prepare_sorted_batch_dev: every testing id of the batch exists once the last sub-batch is parsed, and the
+        // sort of the permutation (dozens of short launches) goes to a stream of its own.  Short shares: beside the chain
+        // kernel.  Long shares: beside the hash and query kernels, BEHIND k_meas -- launches that take wave slots while k_meas
+        // places its three long wavefronts per SIMD cost it 2 ms (31.9 against 29.4 ms per 125 000 reports).
+        const bool sort_here = pl.sort && r + c->cap >= nr && base0 + nr == pl.sort->n;
+        auto start_sort = [&]() -> int32_t {
+            const SortPlan &sp = *pl.sort;
+            HIPCHK(c, hipEventRecord(c->ev_ids, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->stream_sort, c->ev_ids, 0));
+            int e;
+            { KTimer t_(c, WH_K_SORT, c->stream_sort);
+              e = launch_sort_by_id(d_ids, (uint32_t)sp.n, sp.d_order, c->d_sort_tmp, c->d_sort_hist, c->stream_sort);
+              if (!e && sp.d_sorted_ids) e = launch_sort_gather(d_ids, 16, sp.d_order, (uint32_t)sp.n, sp.d_sorted_ids, c->stream_sort); }
+            if (e) { c->err = std::string("sort launch: ") + hipGetErrorString((hipError_t)e); return WH_ERR_HIP; }
+            HIPCHK(c, hipEventRecord(c->ev_sorted, c->stream_sort));
+            return WH_OK;
+        };
+        const bool chain = z.input_len <= c->knobs.v[WH_OPT_CHAIN_MAX_INPUT_LEN];
+        if (sort_here && chain) { const int32_t rc_ = start_sort(); if (rc_) return rc_; }
+        if (chain) {
             // short measurement shares: every sponge of the batch in one launch (chain.hip), then the query
             { KTimer t_(c, WH_K_CHAIN);
-            launch_chain(c->P, c->W, npad, c->knobs.v[WH_OPT_CHAIN_PREFETCH] != 0, pl.vk0, pl.vk1, c->d_aes, d_ids + 16 * base,
-                         d_status + base, c->stream); }
+            launch_chain(c->P, c->W, npad, c->knobs.v[WH_OPT_CHAIN_PREFETCH] != 0, pl.vk0, pl.vk1, d_status + base, c->stream); }
             { KTimer t_(c, WH_K_QUERY);
             hipLaunchKernelGGL(q.fn, query_grid(q, nb), dim3(64 * q.waves), q.lds, c->stream, c->P, c->W,
                                tags_b, out_b, d_status + base); }
@@ -537,7 +565,7 @@ static int32_t prepare_range(wh_ctx *c, const PrepPlan &pl, const uint8_t *d_blo
         if (b_third) HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
         if (hash_b_side)
             hipLaunchKernelGGL(k_hash, dim3(npad / 256), dim3(256), 0, b_third ? c->stream3 : s2, c->P, c->W, npad, 1u, pl.vk0, pl.vk1,
-                               c->d_aes, d_ids + 16 * base, d_status + base);
+                               d_status + base);
         if (b_third) HIPCHK(c, hipEventRecord(c->ev_join3, c->stream3));
         if (side) HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
         { KTimer t_(c, WH_K_MEAS);
@@ -545,11 +573,12 @@ static int32_t prepare_range(wh_ctx *c, const PrepPlan &pl, const uint8_t *d_blo
         // reports whose share stream had a rejected chunk (none, in practice): the general path
         launch_expand(c->P, c->W, npad, 2, c->stream);
         launch_meas(c->P, c->W, 1, npad, d_status + base, c->stream);
+        if (sort_here) { const int32_t rc_ = start_sort(); if (rc_) return rc_; }
         if (side) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         if (b_third) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join3, 0));
         { KTimer t_(c, WH_K_HASH);
         hipLaunchKernelGGL(k_hash, dim3((hash_b_side ? 1 : 2) * npad / 256), dim3(256), 0, c->stream, c->P, c->W, npad,
-                           hash_b_side ? 0u : 2u, pl.vk0, pl.vk1, c->d_aes, d_ids + 16 * base, d_status + base); }
+                           hash_b_side ? 0u : 2u, pl.vk0, pl.vk1, d_status + base); }
         { KTimer t_(c, WH_K_QUERY);
         hipLaunchKernelGGL(q.fn, query_grid(q, nb), dim3(64 * q.waves), q.lds, c->stream, c->P, c->W,
                            tags_b, out_b, d_status + base); }
@@ -574,6 +603,37 @@ int32_t wh_prio3_prepare_batch_dev(wh_ctx *c, const uint8_t verify_key[16], cons
     int32_t rc;
     if ((rc = prepare_begin(c, verify_key, n, n, d_status, pl))) return rc;
     if ((rc = prepare_range(c, pl, d_blob, d_offsets, n, 0, d_tags, d_ids, d_status))) return rc;
+    return prepare_end(c, d_status, n);
+}
+
+// run_vdaf_prepare up to the group test (main.rs:75-94): wh_prio3_prepare_batch_dev + wh_sort_by_testing_id_dev as one call.  Same
+// outputs as the two calls; the difference is where the sort runs.  The testing ids of the batch exist after the parse kernel,
+// so the sort of the permutation and the gather of the sorted ids -- a few dozen launches, each far too small for the chip --
+// run on a stream of their own beside the sponge kernels instead of behind the query kernel; only the gather of the sorted
+// tags waits for the tags.
+int32_t wh_prio3_prepare_sorted_batch_dev(wh_ctx *c, const uint8_t verify_key[16], const uint8_t *d_blob, const uint64_t *d_offsets,
+                                          uint64_t n, uint8_t *d_tags, uint8_t *d_ids, int32_t *d_status, uint32_t *d_order,
+                                          uint8_t *d_sorted_ids, uint8_t *d_sorted_tags) {
+    if (!c || !verify_key || (n && (!d_blob || !d_offsets || !d_tags || !d_ids || !d_status || !d_order))) return WH_ERR_PARAM;
+    WH_LOCK(c);
+    if (n > (1ull << 28)) return WH_ERR_PARAM;
+    PrepPlan pl;
+    int32_t rc;
+    if ((rc = prepare_begin(c, verify_key, n, n, d_status, pl))) return rc;
+    if (n) {
+        if ((rc = ensure(c, c->d_sort_tmp, c->sort_tmp_cap, n))) return rc;
+        if ((rc = ensure(c, c->d_sort_hist, c->sort_hist_cap, 256 * sort_blocks(n) + 256))) return rc;
+    }
+    const SortPlan sp{n, d_order, d_sorted_ids};
+    pl.sort = &sp;
+    if ((rc = prepare_range(c, pl, d_blob, d_offsets, n, 0, d_tags, d_ids, d_status))) return rc;
+    if (n) {
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_sorted, 0));
+        if (d_sorted_tags) {
+            const int e = launch_sort_gather(d_tags, 16, d_order, (uint32_t)n, d_sorted_tags, c->stream);
+            if (e) { c->err = std::string("sort gather launch: ") + hipGetErrorString((hipError_t)e); return WH_ERR_HIP; }
+        }
+    }
     return prepare_end(c, d_status, n);
 }
 

@@ -1,6 +1,6 @@
 // All SHAKE128 work of a batched report in ONE launch, for circuits whose measurement share is short (Histogram, Average,
 // the servers' SumVec of 128): Prio3::prepare_batched up to the query (batched-flpcp-rs/src/vdaf/prio3.rs:2480-2683,
-// 2807-2862) plus the testing id (server-batch-prio3/src/main.rs:51).
+// 2807-2862); the testing id (server-batch-prio3/src/main.rs:51) comes from the parse kernel.
 //
 // The long-share pipeline (k_expand beside k_meas, then k_hash, meas.hip / kernels.hip) is a chain of launches, each with as
 // many lanes as there are reports: at 100 000 reports that is under two wavefronts per SIMD per launch, every wavefront
@@ -12,7 +12,7 @@
 //                      query-rand part over both proof shares (:2610-2642), query-rand seed and randomness (:2651-2672),
 //                      r^m != 1 (flp.rs:413-419), barycentric weights and power tables of the query kernel
 //   blocks [2B, 3B)    hash of the public parts and its field element (:2808-2840)
-//   blocks [3B, 4B)    RLC coefficients (:2859-2862) and the AES-128 testing id
+//   blocks [3B, 4B)    RLC coefficients (:2859-2862)
 // Workgroups are dispatched in index order, so the longest chains start first and the short ones fill the wave slots that
 // are left: one launch holds 4+ wavefronts per SIMD from 100 000 reports, and nothing waits for another stream.
 // The Helper's shares go through the sampler proper (xof_emit: rejected chunks are skipped where they occur), so there is
@@ -30,7 +30,7 @@ enum : uint32_t {
 // PRIO: SpongeT's priority mode (keccak.hpp)
 template <bool PREFETCH, int PRIO>
 __device__ __forceinline__ void chain_body(const Prio3Dev &P, const Workspace &W, uint32_t npad, uint64_t vk0, uint64_t vk1,
-                                           const uint8_t *aes_rk, uint8_t *testing_ids, int32_t *status) {
+                                           int32_t *status) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t seg = __builtin_amdgcn_readfirstlane(gid / npad);     // npad is a multiple of the block size
     const uint32_t t = gid - seg * npad;
@@ -127,8 +127,6 @@ __device__ __forceinline__ void chain_body(const Prio3Dev &P, const Workspace &W
         const F128 r1m = f_sqr_n(r1, P.log2m), rm = f_sqr_n(r, P.log2m);
         if (f_eq(r1m, f_one()) || f_eq(rm, f_one())) { status[i] = ST_ERR_QUERY_RAND; return; }
         weights_and_tables(P, W, i, r, rm, sc->jr[P.jr_len]);
-    } else if (seg == 3) {
-        aes_testing_id(aes_rk, d.base, testing_ids + 16ull * i);
     }
 }
 
@@ -139,28 +137,26 @@ __device__ __forceinline__ void chain_body(const Prio3Dev &P, const Workspace &W
 #define WH_CHAIN_PRIO_MODE 0
 #endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WH_CHAIN_WAVES, WH_CHAIN_WAVES)))
-k_chain(Prio3Dev P, Workspace W, uint32_t npad, uint64_t vk0, uint64_t vk1, const uint8_t *aes_rk, uint8_t *testing_ids,
-        int32_t *status) {
+k_chain(Prio3Dev P, Workspace W, uint32_t npad, uint64_t vk0, uint64_t vk1, int32_t *status) {
 #if WH_CHAIN_PRIO_MODE == 2     // fixed by chain length: Helper chains 2, Leader chains 1, the short ones 0
     const uint32_t seg = __builtin_amdgcn_readfirstlane(blockIdx.x * blockDim.x / npad);
-    if (seg == 0) chain_body<false, 2>(P, W, npad, vk0, vk1, aes_rk, testing_ids, status);
-    else if (seg == 1) chain_body<false, 1>(P, W, npad, vk0, vk1, aes_rk, testing_ids, status);
-    else chain_body<false, 0>(P, W, npad, vk0, vk1, aes_rk, testing_ids, status);
+    if (seg == 0) chain_body<false, 2>(P, W, npad, vk0, vk1, status);
+    else if (seg == 1) chain_body<false, 1>(P, W, npad, vk0, vk1, status);
+    else chain_body<false, 0>(P, W, npad, vk0, vk1, status);
 #else
-    chain_body<false, WH_CHAIN_PRIO_MODE == 1 ? -1 : 0>(P, W, npad, vk0, vk1, aes_rk, testing_ids, status);
+    chain_body<false, WH_CHAIN_PRIO_MODE == 1 ? -1 : 0>(P, W, npad, vk0, vk1, status);
 #endif
 }
 // the same with the next rate block's loads in flight under the permutation (42 more VGPRs: three wavefronts a SIMD)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
-k_chain_prefetch(Prio3Dev P, Workspace W, uint32_t npad, uint64_t vk0, uint64_t vk1, const uint8_t *aes_rk, uint8_t *testing_ids,
-                 int32_t *status) {
-    chain_body<true, WH_CHAIN_PRIO_MODE == 1 ? -1 : 0>(P, W, npad, vk0, vk1, aes_rk, testing_ids, status);
+k_chain_prefetch(Prio3Dev P, Workspace W, uint32_t npad, uint64_t vk0, uint64_t vk1, int32_t *status) {
+    chain_body<true, WH_CHAIN_PRIO_MODE == 1 ? -1 : 0>(P, W, npad, vk0, vk1, status);
 }
 
-void launch_chain(const Prio3Dev &P, const Workspace &W, uint32_t npad, bool prefetch, uint64_t vk0, uint64_t vk1,
-                  const uint8_t *aes_rk, uint8_t *testing_ids, int32_t *status, hipStream_t stream) {
-    if (prefetch) hipLaunchKernelGGL(k_chain_prefetch, dim3(4 * npad / 256), dim3(256), 0, stream, P, W, npad, vk0, vk1, aes_rk, testing_ids, status);
-    else hipLaunchKernelGGL(k_chain, dim3(4 * npad / 256), dim3(256), 0, stream, P, W, npad, vk0, vk1, aes_rk, testing_ids, status);
+void launch_chain(const Prio3Dev &P, const Workspace &W, uint32_t npad, bool prefetch, uint64_t vk0, uint64_t vk1, int32_t *status,
+                  hipStream_t stream) {
+    if (prefetch) hipLaunchKernelGGL(k_chain_prefetch, dim3(4 * npad / 256), dim3(256), 0, stream, P, W, npad, vk0, vk1, status);
+    else hipLaunchKernelGGL(k_chain, dim3(4 * npad / 256), dim3(256), 0, stream, P, W, npad, vk0, vk1, status);
 }
 
 }  // namespace wh

@@ -50,8 +50,10 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
 // VdafBatchedKey::decode_with_param (vdaf.rs:164-192) as far as structure goes: lengths,
 // agg_id, num_queries.  Field-element range checks happen where the elements are loaded
 // (query kernel).  Trailing bytes are not looked at (server-batch-prio3/src/main.rs:46-47).
+// The testing id of a well-formed report is computed here too (AES-128 of the client id, main.rs:51): the ids of a batch exist
+// before its first sponge runs, so the sort by testing id can run beside the sponge kernels (wh_prio3_prepare_sorted_batch_dev).
 __global__ void k_parse(Prio3Dev P, Workspace W, const uint8_t *blob, const uint64_t *offsets, uint32_t n,
-                        int32_t *status, uint8_t *tags, uint8_t *testing_ids, uint8_t *out_shares) {
+                        int32_t *status, uint8_t *tags, uint8_t *testing_ids, uint8_t *out_shares, const uint8_t *aes_rk) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint8_t *rep = blob + offsets[i];
@@ -104,7 +106,9 @@ __global__ void k_parse(Prio3Dev P, Workspace W, const uint8_t *blob, const uint
         F128 *out_row = reinterpret_cast<F128 *>(out_shares) + (uint64_t)i * P.output_len;
         for (uint32_t e = 0; e < P.output_len; e++) out_row[e] = f_zero();
         st128(tags + 16ull * i, f_zero());
-        st128(testing_ids + 16ull * i, f_zero());      // k_hash skips the report: without this the id is whatever the buffer held
+        st128(testing_ids + 16ull * i, f_zero());      // an undecodable report has no id: zero, whatever the buffer held
+    } else {
+        aes_testing_id(aes_rk, rep, testing_ids + 16ull * i);
     }
     W.desc[i] = d;
     status[i] = st;
@@ -133,11 +137,10 @@ __global__ void k_parse(Prio3Dev P, Workspace W, const uint8_t *blob, const uint
 //   randomness (:2580-2585), own query-rand part (:2610-2642), query-rand seed (:2651-2665, which
 //   reuses DST_JR_SEED), query randomness (:2667-2672) -- then the barycentric weights.
 // Job B (lanes [npad, 2 npad)): hash of the public parts (:2808-2840), RLC coefficients
-//   (:2859-2862), testing id (main.rs:51).
+//   (:2859-2862).  (The testing id, main.rs:51, comes from the parse kernel.)
 // All sponges of a lane go through one loop body; a wave-uniform switch picks the inputs.
 __global__ void __launch_bounds__(256) WH_HASH_ATTR k_hash(Prio3Dev P, Workspace W, uint32_t npad, uint32_t jobs, uint64_t vk0,
-                                              uint64_t vk1, const uint8_t *aes_rk, uint8_t *testing_ids,
-                                              int32_t *status) {
+                                              uint64_t vk1, int32_t *status) {
     uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
     // jobs: 0 = A only, 1 = B only, 2 = A in lanes [0, npad) and B in [npad, 2 npad)
     uint32_t which = jobs == 2 ? job >= npad : jobs;
@@ -206,8 +209,6 @@ __global__ void __launch_bounds__(256) WH_HASH_ATTR k_hash(Prio3Dev P, Workspace
         F128 r1m = f_sqr_n(r1, P.log2m), rm = f_sqr_n(r, P.log2m);
         if (f_eq(r1m, f_one()) || f_eq(rm, f_one())) { status[i] = ST_ERR_QUERY_RAND; return; }
         weights_and_tables(P, W, i, r, rm, sc->jr[P.jr_len]);
-    } else {
-        aes_testing_id(aes_rk, d.base, testing_ids + 16ull * i);
     }
 }
 

@@ -289,6 +289,14 @@ class Prio3:
                                                  d_status), "prepare_batch_dev")
         self.n_last = n
 
+    def prepare_sorted_batch_dev(self, verify_key, d_blob, d_offsets, n, d_tags, d_ids, d_status, d_order, d_sorted_ids=None, d_sorted_tags=None):
+        """prepare_batch_dev + sort_by_testing_id_dev in one call (run_vdaf_prepare up to the group test, main.rs:75-94): the sort
+        runs beside the sponge kernels.  Same outputs as the two calls."""
+        vk = np.frombuffer(bytes(verify_key), dtype=np.uint8)
+        self._chk(lib.wh_prio3_prepare_sorted_batch_dev(self._ctx, vk.ctypes.data, d_blob, d_offsets, n, d_tags, d_ids, d_status, d_order,
+                                                        d_sorted_ids, d_sorted_tags), "prepare_sorted_batch_dev")
+        self.n_last = n
+
     def sort_by_testing_id_dev(self, d_ids, n, d_order, d_tags=None, tag_bytes=16, d_sorted_ids=None, d_sorted_tags=None):
         """The servers' stable sort by testing id (main.rs:93) on device buffers (raw pointers); asynchronous."""
         self._chk(lib.wh_sort_by_testing_id_dev(self._ctx, d_ids, n, d_order, d_tags, tag_bytes, d_sorted_ids, d_sorted_tags),
