@@ -222,11 +222,22 @@ __device__ __forceinline__ F128 ld128g(const uint8_t *p) {
     const wh_u32x4 t = *(const __attribute__((address_space(1))) wh_u32x4_u1 *)p;
     return F128{t.x | ((uint64_t)t.y << 32), t.z | ((uint64_t)t.w << 32)};
 }
+// the same with the non-temporal hint: a stream that is read (written) once and must not push other lines out of L2
+__device__ __forceinline__ F128 ld128g_nt(const uint8_t *p) {
+    const wh_u32x4 t = __builtin_nontemporal_load((const __attribute__((address_space(1))) wh_u32x4_u1 *)p);
+    return F128{t.x | ((uint64_t)t.y << 32), t.z | ((uint64_t)t.w << 32)};
+}
+__device__ __forceinline__ void st128g_nt(uint8_t *p, const F128 &v) {
+    const wh_u32x4 t = {(uint32_t)v.lo, (uint32_t)(v.lo >> 32), (uint32_t)v.hi, (uint32_t)(v.hi >> 32)};
+    __builtin_nontemporal_store(t, (__attribute__((address_space(1))) wh_u32x4_u1 *)p);
+}
 __device__ __forceinline__ void st128g(uint8_t *p, const F128 &v) {
     const wh_u32x4 t = {(uint32_t)v.lo, (uint32_t)(v.lo >> 32), (uint32_t)v.hi, (uint32_t)(v.hi >> 32)};
     *(__attribute__((address_space(1))) wh_u32x4_u1 *)p = t;
 }
 #else
+WH_HD F128 ld128g_nt(const uint8_t *p) { return ld128(p); }
+WH_HD void st128g_nt(uint8_t *p, const F128 &v) { st128(p, v); }
 WH_HD uint64_t ld64g(const uint8_t *p) { return ld64(p); }
 WH_HD uint8_t ld8g(const uint8_t *p) { return *p; }
 WH_HD F128 ld128g(const uint8_t *p) { return ld128(p); }

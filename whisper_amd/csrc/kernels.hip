@@ -792,14 +792,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WH_Q_W
         sh->sum_x[wave] = sx;
         sh->bad[wave] = bad;
     }
-    // what the last step (one lane) multiplies: fetched ahead of the barrier instead of one latency per product behind it
-    const uint32_t vl_ = P.verifier_len;
-    F128 fin[9];
+    // the last step's operands, one set per lane te < 8 of the first wave, fetched ahead of the barrier:
+    //   te 0: rlc[0] (v[0] - pp1[0])      te 1: rlc[1 + arity] (G(r) - pp1[1 + arity])   te 2, 3: decide flags -> rlc[vl], rlc[vl + 1]
+    //   te 4, 5: rand_diff -> rlc[vl + 2], rlc[vl + 3]      te 6: rlc[vl + 4] (+-hash)      te 7: the wire part of the tag
+    const uint32_t vl_ = P.verifier_len, te = lane & 7;
+    F128 t_rlc = f_zero(), t_q = f_zero(), hs = f_zero();
+    uint32_t t_flag = 0;
     if (!BASE && wave == 0) {
-        fin[0] = ld128g(pp1); fin[1] = ld128g(pp1 + 16ull * (1 + P.arity));
-        fin[2] = rlc[0]; fin[3] = rlc[1 + P.arity];
-#pragma unroll
-        for (int q = 0; q < 5; q++) fin[4 + q] = rlc[vl_ + q];
+        t_rlc = rlc[te == 0 ? 0 : (te == 1 ? 1 + P.arity : vl_ + (te < 7 ? te - 2 : 0))];
+        t_q = ld128g(pp1 + 16ull * (te == 1 ? 1 + P.arity : 0));
+        hs = sc->hash;
+        t_flag = sc->rand_diff[te == 5];
     }
     __syncthreads();
     bad = 0;
@@ -808,36 +811,36 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WH_Q_W
         for (uint32_t e = threadIdx.x; e < P.output_len; e += blockDim.x) out_row[e] = f_zero();
         if (BASE) for (uint32_t e = threadIdx.x; e < P.ver_stride; e += blockDim.x) ver_row[e] = f_zero();
     }
-    if (threadIdx.x == 0) {
-        const uint32_t vl = P.verifier_len;
-        tag = f_zero();
-        sx = f_zero();
-        for (uint32_t w = 0; w < S; w++) { tag = f_add(tag, sh->tag[w]); sx = f_add(sx, sh->sum_x[w]); }
-        if (HIST) {
-            // types.rs:428-436: rho' * range_check + rho'^2 * (sum x - h)
-            F128 rho2 = sc->jr[P.jr_len + 1];
-            v0 = f_add(f_mul(rho2, v0), f_mul(f_sqr(rho2), f_sub(sx, P.half)));
-        }
-        if (BASE) {
-            // Prio3PrepareShare (prio3.rs:1953-1970): verifier share | joint-rand part
+    if (wave != 0) return;
+    tag = f_zero();
+    sx = f_zero();
+    for (uint32_t w = 0; w < S; w++) { tag = f_add(tag, sh->tag[w]); sx = f_add(sx, sh->sum_x[w]); }
+    if (HIST) {
+        // types.rs:428-436: rho' * range_check + rho'^2 * (sum x - h)
+        const F128 rho2 = sc->jr[P.jr_len + 1];
+        v0 = f_add(f_mul(rho2, v0), f_mul(f_sqr(rho2), f_sub(sx, P.half)));
+    }
+    if (BASE) {
+        // Prio3PrepareShare (prio3.rs:1953-1970): verifier share | joint-rand part
+        if (lane == 0) {
             if (bad) status[i] = ST_ERR_MODULUS;
-            else { ver_row[0] = v0; ver_row[1 + P.arity] = g_at_r; if (P.ver_stride > vl) ver_row[vl] = sc->own; }
-            return;
+            else { ver_row[0] = v0; ver_row[1 + P.arity] = g_at_r; if (P.ver_stride > vl_) ver_row[vl_] = sc->own; }
         }
-        F128 q0 = fin[0], qg = fin[1];
-        F128 d0 = leader ? f_sub(v0, q0) : v0;
-        F128 dg = leader ? f_sub(g_at_r, qg) : g_at_r;
-        tag = f_add(tag, f_mul(fin[2], d0));
-        tag = f_add(tag, f_mul(fin[3], dg));
-        tag = f_add(tag, f_mul(fin[4], sh->dec[0]));
-        tag = f_add(tag, f_mul(fin[5], sh->dec[1]));
-        if (sc->rand_diff[0]) tag = f_add(tag, fin[6]);
-        if (sc->rand_diff[1]) tag = f_add(tag, fin[7]);
-        F128 hs = leader ? f_neg(sc->hash) : sc->hash;       // prio3.rs:2844-2855
-        tag = f_add(tag, f_mul(fin[8], hs));
-        if (bad) { status[i] = ST_ERR_MODULUS; tag = f_zero(); }
+        return;
+    }
+    // eight lanes side by side, one multiplication deep (it was one lane doing ten in a row)
+    const F128 dv = te == 0 ? v0 : g_at_r;
+    const F128 mb = te < 2 ? (leader ? f_sub(dv, t_q) : dv) : (leader ? f_neg(hs) : hs);     // share of zero: Leader -H, Helper +H (prio3.rs:2844-2855)
+    F128 term = f_mul(t_rlc, mb);
+    if (te == 2 || te == 3) term = f_is_zero(sh->dec[te - 2]) ? f_zero() : t_rlc;
+    if (te == 4 || te == 5) term = t_flag ? t_rlc : f_zero();
+    if (te == 7) term = tag;
+#pragma unroll
+    for (int msk = 4; msk >= 1; msk >>= 1) term = f_add(term, shfl_xor_f(term, msk));
+    if (lane == 0) {
+        if (bad) { status[i] = ST_ERR_MODULUS; term = f_zero(); }
         // prepare_encoded_key: the Helper-role tag is negated (main.rs:53-59)
-        st128(tag_out, leader ? tag : f_neg(tag));
+        st128(tag_out, leader ? term : f_neg(term));
     }
 }
 

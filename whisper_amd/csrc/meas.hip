@@ -37,13 +37,22 @@ __device__ __forceinline__ void xor_shifted(uint64_t &b, const W2 &cur, uint32_t
 }
 
 enum : uint32_t { LANE_FULL = 0, LANE_SQUEEZE = 1, LANE_ABSORB = 2 };
+#ifdef WH_MEAS_NT_STORES
+#define WH_MEAS_ST st128g_nt
+#else
+#define WH_MEAS_ST st128g
+#endif
 
 // (wave_slot / rotate_prio: keccak.hpp)
 // one rate block as ten 16-byte loads and one 8-byte load (any alignment)
 __device__ __forceinline__ void load_block(uint64_t (&w)[RATE_WORDS], const uint8_t *p) {
 #pragma unroll
     for (int i = 0; i < 10; i++) {
+#ifdef WH_MEAS_NT_LOADS
+        const F128 t = ld128g_nt(p + 16 * i);
+#else
         const F128 t = ld128g(p + 16 * i);
+#endif
         w[2 * i] = t.lo; w[2 * i + 1] = t.hi;
     }
     w[20] = ld64g(p + 160);
@@ -162,7 +171,7 @@ __device__ __forceinline__ void meas_body(const Prio3Dev &P, const Workspace &W,
             }
             if (even) {
 #pragma unroll
-                for (int c = 0; c < 10; c++) st128g(out + 16 * c, F128{s.st[2 * c], s.st[2 * c + 1]});
+                for (int c = 0; c < 10; c++) WH_MEAS_ST(out + 16 * c, F128{s.st[2 * c], s.st[2 * c + 1]});
             }
             const uint64_t carry = s.st[20];
             keccak_f1600_ranked(s.st, rank);
@@ -192,9 +201,9 @@ __device__ __forceinline__ void meas_body(const Prio3Dev &P, const Workspace &W,
                 for (int c = 0; c < 10; c++) WH_EXACT(s.st[2 * c + 1], s.st[2 * c + 2]);
             }
             if (even) {
-                st128g(out + 160, F128{carry, s.st[0]});
+                WH_MEAS_ST(out + 160, F128{carry, s.st[0]});
 #pragma unroll
-                for (int c = 0; c < 10; c++) st128g(out + 176 + 16 * c, F128{s.st[2 * c + 1], s.st[2 * c + 2]});
+                for (int c = 0; c < 10; c++) WH_MEAS_ST(out + 176 + 16 * c, F128{s.st[2 * c + 1], s.st[2 * c + 2]});
             }
             out += 336;
             keccak_f1600_ranked(s.st, rank);
