@@ -394,7 +394,7 @@ enum {
     WH_OPT_BASE_PAIRED = 8,         /* 0 if WH_BASE_NO_MEAS is set: prepare_init expands, then absorbs, in two passes */
     WH_OPT_CHAIN_MAX_INPUT_LEN = 9, /* WH_CHAIN_MAX_INPUT_LEN: circuits with input_len up to this run all their sponges in one
                                      * launch (chain.hip) instead of the k_meas pipeline */
-    WH_OPT_CHAIN_PREFETCH = 10,     /* WH_CHAIN_PREFETCH: 1 = that launch keeps the next rate block's loads in flight (3 waves/SIMD) */
+    WH_OPT_CHAIN_PREFETCH = 10,     /* WH_CHAIN_PREFETCH: 1 (default) = that launch keeps the next rate block's loads in flight (3 waves/SIMD), 0 = 4 waves/SIMD without */
     WH_OPT_QUERY_TINY = 11,         /* WH_QUERY_TINY: 0 = circuits of at most two gadget calls of at most 64 slots take the general
                                      * query kernel instead of the one-wavefront-per-report one */
     WH_NUM_OPTS = 12
