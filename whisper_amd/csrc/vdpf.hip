@@ -214,16 +214,31 @@ __device__ __forceinline__ void sha_of_pi_hex(const uint32_t (&pi)[16], uint32_t
 
 // ------------------------------------------------------------------------------------------ main key
 // Persistent workgroups of 1024 lanes, one per CU, each walking over key chains blockIdx.x, + gridDim.x, ...  The AES
-// tables take NT * 32 KiB of the CU's 160 KiB (four tables up to 512 buckets, two above).  The last wavefront is the
-// PRODUCER: while the other fifteen turn key chain k into buckets it copies and checks the header of key chain k + G,
-// computes its testing id and expands its tree into the other seed buffer -- work that is a chain of AES latencies
-// (two per level and 64-node pass) and would otherwise leave the CU idle.  One barrier per key chain.
-constexpr uint32_t MAIN_THREADS = 1024, CONSUMERS = MAIN_THREADS - 64;
+// tables take NT * 32 KiB of the CU's 160 KiB (four tables up to 512 buckets, two above).  There is no barrier per key
+// chain; the sixteen wavefronts are a PRODUCER and fifteen CONSUMERS that meet through counters in LDS:
+//
+//   producer   copies and checks the header of the workgroup's c-th key chain, computes its testing id and expands the
+//              narrow top of its tree, levels 0 .. depth - SP (a chain of AES latencies that would leave the CU idle),
+//              into one of three (header, node) buffers, two key chains ahead of the consumers;
+//   consumers  take work units from a counter.  Stage st holds the units of two key chains: the leaves of key chain
+//              st - 1 -- leaf hashes (64 leaves a unit), conversion into buckets (two leaves a unit, lane = counter, so
+//              a leaf is one 1 KiB coalesced store), sign_data and ctr (64 leaves) -- and, placed before the last
+//              conversion units so that they are finished when the stage is, the wide bottom of the tree of key chain
+//              st: SP levels under 64 nodes per unit, all in registers, into the other of two leaf buffers.
+//              A wavefront goes on to the next stage as soon as the counter runs out; the last one to leave a stage
+//              writes the sums over the leaves and hands the buffers back.
+//
+// Measured (profiles/r3_hh_queue.txt): the barrier version left the LDS pipe 61-66 % busy; taking the producer's work away
+// altogether gained 12 % on it, a work counter alone 10 % at 512 buckets and -2 % at 2 048 (the producer, slowed by a
+// now always busy LDS pipe, became the critical path: 74 AES latencies per tree there).
+constexpr uint32_t MAIN_THREADS = 1024, CONSUMERS = MAIN_THREADS - 64, HH_SPLIT = 2;
+__host__ __device__ constexpr uint32_t hh_split(uint32_t depth) { return depth < HH_SPLIT ? depth : HH_SPLIT; }
 
-// header copy, checks, testing id and tree of key chain i into (hdr, seeds); one wavefront, no workgroup barrier inside
+// header copy, checks, testing id and the tree's levels 0 .. levels of key chain i into (hdr, nodes, cbits): level l has 2^l
+// nodes at nodes[0 .. 2^l); one wavefront, no workgroup barrier inside
 template <int NT>
 __device__ __forceinline__ bool hh_prepare(const TabRef &T, const HhTables *__restrict__ tab, const uint8_t *kb, uint32_t depth,
-                                            uint32_t lane, uint8_t *hdr, uint4 *seeds, uint8_t *cbits, uint8_t *id_out) {
+                                            uint32_t levels, uint32_t lane, uint8_t *hdr, uint4 *seeds, uint8_t *cbits, uint8_t *id_out) {
     const HhLayout L(depth);
     const uint32_t *rk0 = tab->rk[0];
     for (uint32_t k = lane; k < L.sup; k += 64) hdr[k] = kb[k];
@@ -249,9 +264,9 @@ __device__ __forceinline__ bool hh_prepare(const TabRef &T, const HhTables *__re
     }
     ok = __all(ok);
     if (!ok) return false;
-    // tree: level l has 2^l nodes at seeds[0 .. 2^l); the children of node p go to 2p and 2p+1, in place, from the last
-    // 64-parent pass down so that children never land on parents still to be read
-    for (uint32_t l = 0; l < depth; l++) {
+    // the children of node p go to 2p and 2p+1, in place, from the last 64-parent pass down so that children never land
+    // on parents still to be read
+    for (uint32_t l = 0; l < levels; l++) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const B128 cw = ldb128(hdr + L.cw + 18 * l);
         const uint32_t cb0 = hdr[L.cw + 18 * l + 16], cb1 = hdr[L.cw + 18 * l + 17];
@@ -298,6 +313,20 @@ struct HhSketchOut {
 };
 __device__ __forceinline__ void sk_add(uint32_t *p, uint32_t v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// counters in LDS, all written by lane 0 of a wavefront
+enum : uint32_t {
+    Q_WORK = 0,        // [2] next work unit of stage st, at st & 1
+    Q_LEFT_N = 2,      // [2] consumers that have left stage st
+    Q_TREE = 4,        // [2] tree units finished for the leaf buffer
+    Q_READY = 6,       // key chains the producer has published
+    Q_LEFT = 7,        // stages every consumer has left
+    Q_WORDS = 8
+};
+__device__ __forceinline__ void q_wait(const uint32_t *p, uint32_t v) {
+    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) __builtin_amdgcn_s_sleep(4);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 template <int NT>
 __global__ __launch_bounds__(1024) void k_hh_main(const uint8_t *__restrict__ keys, uint64_t stride, uint32_t n, uint32_t depth,
                                                   const HhTables *__restrict__ tab, uint32_t *__restrict__ dat,
@@ -305,147 +334,237 @@ __global__ __launch_bounds__(1024) void k_hh_main(const uint8_t *__restrict__ ke
                                                   uint8_t *__restrict__ ids, int32_t *__restrict__ status, HhSketchOut so) {
     extern __shared__ uint32_t lds[];
     const uint32_t N = 1u << depth, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t SP = hh_split(depth), NP = N >> SP;                    // nodes of level depth - SP: the producer's last
     uint32_t *Tall = lds;
-    uint4 *seeds_b = reinterpret_cast<uint4 *>(lds + NT * T_WORDS);     // [2][N]
-    uint8_t *hdr_b = reinterpret_cast<uint8_t *>(seeds_b + 2 * N);       // [2][HDR_BYTES]
-    uint32_t *red_b = reinterpret_cast<uint32_t *>(hdr_b + 2 * HDR_BYTES);  // [2][260] sums over the leaves
-    uint32_t *okf = red_b + 520;                                          // [2]
-    uint8_t *cbits = reinterpret_cast<uint8_t *>(okf + 4);                // control bits of the level being expanded
+    uint4 *seeds_b = reinterpret_cast<uint4 *>(lds + NT * T_WORDS);      // [2][N] leaves
+    uint4 *nodes_b = seeds_b + 2 * N;                                     // [3][NP] the producer's tree
+    uint8_t *hdr_b = reinterpret_cast<uint8_t *>(nodes_b + 3 * NP);      // [3][HDR_BYTES]
+    uint32_t *red_b = reinterpret_cast<uint32_t *>(hdr_b + 3 * HDR_BYTES);  // [2][260] sums over the leaves
+    uint32_t *okf = red_b + 520;                                          // [3] (+1)
+    uint32_t *qs = okf + 4;                                               // [Q_WORDS]
+    uint8_t *id_lds = reinterpret_cast<uint8_t *>(qs + Q_WORDS);          // [16] testing id of a subtract launch (nowhere to put it)
+    uint8_t *cbits_b = id_lds + 16;                                       // [3][NP] control bits of the producer's nodes
     const HhLayout L(depth);
     const bool producer = wv == MAIN_THREADS / 64 - 1;
 
     fill_table<NT>(Tall, tab, tid, MAIN_THREADS);
     if (tid < 520) red_b[tid] = 0;
+    if (tid < Q_WORDS) qs[tid] = 0;
     __syncthreads();
     const TabRef T = tab_ref(Tall, tid);
     const uint32_t *rk0 = tab->rk[0];
     const uint32_t G = gridDim.x;
     const uint64_t words = (uint64_t)N * HH_BKT;
-    // a subtract launch has nowhere to put testing ids (the caller has them): the producer writes them into LDS instead
-    __shared__ uint8_t id_lds[16];
     // `keys` starts at the launch's first key chain (kidx == NULL) or is the caller's whole array (kidx != NULL)
     auto key_slot = [&](uint32_t k) -> uint64_t { return so.kidx ? so.kidx[k] : k; };
     auto key_index = [&](uint32_t k) -> uint64_t { return so.kidx ? so.kidx[k] : so.first + k; };
     uint32_t *sk_base = so.sketch;
+    const uint32_t C = (n - blockIdx.x + G - 1) / G;      // key chains of this workgroup (grid <= n)
+    auto post = [&](uint32_t *p, uint32_t v) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
 
     if (producer) {
-        const uint32_t k = blockIdx.x;
-        const bool ok = hh_prepare<NT>(T, tab, keys + key_slot(k) * stride, depth, lane, hdr_b, seeds_b, cbits, ids ? ids + 16ull * k : id_lds);
-        if (lane == 0) { okf[0] = ok; if (status) status[k] = ok ? 0 : HH_ERR_KEY_FORMAT; }
-    }
-    __syncthreads();
-
-    uint32_t cur = 0;
 #pragma unroll 1
-    for (uint32_t k = blockIdx.x; k < n; k += G, cur ^= 1) {
-        uint4 *seeds = seeds_b + cur * N;
-        const uint8_t *hdr = hdr_b + cur * HDR_BYTES;
-        uint32_t *red = red_b + cur * 260;
-        const uint64_t leaf0 = (uint64_t)k * N;
-        if (producer) {
-            const uint32_t kn = k + G;
-            if (kn < n) {
-                const bool ok = hh_prepare<NT>(T, tab, keys + key_slot(kn) * stride, depth, lane, hdr_b + (cur ^ 1) * HDR_BYTES,
-                                               seeds_b + (cur ^ 1) * N, cbits, ids ? ids + 16ull * kn : id_lds);
-                if (lane == 0) { okf[cur ^ 1] = ok; if (status) status[kn] = ok ? 0 : HH_ERR_KEY_FORMAT; }
-            }
-        } else if (!okf[cur]) {
-            if (dat) {
-                uint32_t *d = dat + leaf0 * HH_BKT;
-                for (uint64_t q = tid; q < words; q += CONSUMERS) d[q] = 0;
-            }
-        } else {
-            const bool negate = (hdr[L.key_id] != 0) != (so.flip != 0);
-            uint32_t *sk = sk_base ? sk_base + (key_index(k) / so.group_size) * words : nullptr;
-            // ---- per-leaf pieces that occupy one lane each, as one work list of 2N items:
-            //  items [0, N): tilde_pi = mmo_hash2to4(seed, x) with x = IntModN::zero() at EVERY leaf (IntModN::one() has
-            //    val 0, common/src/group.rs:448-453, so `x.add(&GIn::one())` never moves), corrected by cs when lsb(seed) = 1;
-            //  items [N, 2N): sign_data and ctr of the converted bucket = the first 8 bytes of counter seed+64.
-            {
-                const uint32_t oc0 = ldb32(hdr + L.oc + 1024), oc1 = ldb32(hdr + L.oc + 1028);
-                uint32_t t0 = 0, t1 = 0;
-#pragma unroll 1
-                for (uint32_t it = tpc ? tid : N + tid; it < 2 * N; it += CONSUMERS) {
-                    const uint32_t x = it & (N - 1);
-                    const uint4 s = seeds[x];
-                    const uint32_t m = 0u - (s.x & 1);
-                    B128 c = {{s.x, s.y, s.z, s.w}};
-                    if (it < N) {
-                        const B128 s1 = mmo<NT>(T, rk0, c);
-                        const B128 s3 = mmo<NT>(T, rk0, s1);
-                        const uint8_t *cs = hdr + L.cs;
-                        uint4 *o = tpc + (leaf0 + x) * 4;
-                        B128 q = ldb128(cs);
-                        o[0] = make_uint4(tab->cx[0][0] ^ (q.w[0] & m), tab->cx[0][1] ^ (q.w[1] & m), tab->cx[0][2] ^ (q.w[2] & m), tab->cx[0][3] ^ (q.w[3] & m));
-                        q = ldb128(cs + 16);
-                        o[1] = make_uint4(s1.w[0] ^ (q.w[0] & m), s1.w[1] ^ (q.w[1] & m), s1.w[2] ^ (q.w[2] & m), s1.w[3] ^ (q.w[3] & m));
-                        q = ldb128(cs + 32);
-                        o[2] = make_uint4(tab->cx[0][4] ^ (q.w[0] & m), tab->cx[0][5] ^ (q.w[1] & m), tab->cx[0][6] ^ (q.w[2] & m), tab->cx[0][7] ^ (q.w[3] & m));
-                        q = ldb128(cs + 48);
-                        o[3] = make_uint4(s3.w[0] ^ (q.w[0] & m), s3.w[1] ^ (q.w[1] & m), s3.w[2] ^ (q.w[2] & m), s3.w[3] ^ (q.w[3] & m));
-                    } else {
-                        ctr_add(c, 64);
-                        const B128 o = mmo<NT>(T, rk0, c);
-                        uint32_t a = o.w[0] + (oc0 & m), b = o.w[1] + (oc1 & m);
-                        if (negate) { a = 0u - a; b = 0u - b; }
-                        if (dat) *reinterpret_cast<uint2 *>(dat + (leaf0 + x) * HH_BKT + 256) = make_uint2(a, b);
-                        if (sk) { sk_add(sk + (uint64_t)x * HH_BKT + 256, a); sk_add(sk + (uint64_t)x * HH_BKT + 257, b); }
-                        t0 += a; t1 += b;
-                    }
-                }
-                if (t0 | t1) { atomicAdd(&red[256], t0); atomicAdd(&red[257], t1); }
-            }
-            // ---- convert::<Bucket<u32>>: 1032 bytes = counters seed+0 .. seed+64 (the last half used, above); one
-            // wavefront per leaf, lane j takes counter j, so a leaf is one 1 KiB coalesced store; the sum over leaves
-            // stays in registers
-            {
-                const B128 oc = ldb128(hdr + L.oc + 16 * lane);
-                uint32_t acc[4] = {0, 0, 0, 0};
-                constexpr uint32_t CW = CONSUMERS / 64;
-                // two leaves per pass: 32 table reads in flight per round instead of 16 keeps the LDS queue fed
-#pragma unroll 1
-                for (uint32_t x = wv; x < N; x += 2 * CW) {
-                    const uint32_t x1 = x + CW < N ? x + CW : x;   // the odd leaf out is computed twice, stored once
-                    const uint4 sa = seeds[x], sb = seeds[x1];
-                    B128 ca = {{sa.x, sa.y, sa.z, sa.w}}, cb = {{sb.x, sb.y, sb.z, sb.w}};
-                    ctr_add(ca, lane); ctr_add(cb, lane);
-                    B128 oa, ob;
-                    mmo2<NT>(T, rk0, ca, cb, oa, ob);
-                    const uint32_t ma = 0u - (sa.x & 1), mb = 0u - (sb.x & 1);
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        oa.w[q] += oc.w[q] & ma; ob.w[q] += oc.w[q] & mb;
-                        if (negate) { oa.w[q] = 0u - oa.w[q]; ob.w[q] = 0u - ob.w[q]; }
-                        acc[q] += oa.w[q];
-                        if (x1 != x) acc[q] += ob.w[q];
-                    }
-                    if (dat) {
-                        uint2 *d = reinterpret_cast<uint2 *>(dat + (leaf0 + x) * HH_BKT + 4 * lane);  // 8-byte aligned only
-                        d[0] = make_uint2(oa.w[0], oa.w[1]);
-                        d[1] = make_uint2(oa.w[2], oa.w[3]);
-                        if (x1 != x) {
-                            d = reinterpret_cast<uint2 *>(dat + (leaf0 + x1) * HH_BKT + 4 * lane);
-                            d[0] = make_uint2(ob.w[0], ob.w[1]);
-                            d[1] = make_uint2(ob.w[2], ob.w[3]);
-                        }
-                    }
-                    if (sk) {
-                        uint32_t *pa = sk + (uint64_t)x * HH_BKT + 4 * lane, *pb = sk + (uint64_t)x1 * HH_BKT + 4 * lane;
-#pragma unroll
-                        for (int q = 0; q < 4; q++) sk_add(pa + q, oa.w[q]);
-                        if (x1 != x) {
-#pragma unroll
-                            for (int q = 0; q < 4; q++) sk_add(pb + q, ob.w[q]);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 4; q++) atomicAdd(&red[4 * lane + q], acc[q]);
-            }
+        for (uint32_t c = 0; c < C; c++) {
+            // buffer c % 3 held key chain c - 3, whose leaves are the business of stage c - 2
+            if (c >= 3) q_wait(&qs[Q_LEFT], c - 1);
+            const uint32_t k = blockIdx.x + c * G, h = c % 3;
+            const bool ok = hh_prepare<NT>(T, tab, keys + key_slot(k) * stride, depth, depth - SP, lane, hdr_b + h * HDR_BYTES,
+                                           nodes_b + h * NP, cbits_b + h * NP, ids ? ids + 16ull * k : id_lds);
+            if (lane == 0) { okf[h] = ok; if (status) status[k] = ok ? 0 : HH_ERR_KEY_FORMAT; }
+            post(&qs[Q_READY], c + 1);
         }
-        __syncthreads();
-        // this buffer's sums are complete; it is used again two key chains on, a barrier away
-        if (tid < HH_BKT) { if (buckg) buckg[(uint64_t)k * HH_BKT + tid] = red[tid]; red[tid] = 0; }
+        return;
+    }
+
+    const uint32_t TU = (NP + 63) >> 6;                   // tree units of a key chain
+    const uint32_t U2 = (N + 63) >> 6, U1 = tpc ? U2 : 0, H = (N + 1) >> 1;
+    // the tree units go before the last HT conversion units: late enough for the producer, early enough to be done
+    const uint32_t HT = H < 4 * (CONSUMERS / 64) ? H / 2 : 3 * (CONSUMERS / 64), H1 = H - HT;
+#pragma unroll 1
+    for (uint32_t st = 0; st <= C; st++) {
+        const uint32_t b = st & 1;
+        // the counters at b belonged to stage st - 2
+        if (st >= 2) q_wait(&qs[Q_LEFT], st - 1);
+        if (st >= 1) q_wait(&qs[Q_READY], st);            // (its tree units were taken a stage ago, perhaps not yet started)
+        const bool has_tree = st < C;                     // key chain st: buffers st % 3, leaves into st & 1
+        const uint32_t c = st - 1, hb = c % 3, lb = c & 1;  // key chain of the leaves (st >= 1)
+        const uint32_t k = blockIdx.x + c * G;
+        const bool leaves = st >= 1 && okf[st >= 1 ? hb : 0];
+        uint4 *seeds = seeds_b + lb * N;
+        const uint8_t *hdr = hdr_b + hb * HDR_BYTES;
+        uint32_t *red = red_b + lb * 260;
+        const uint64_t leaf0 = (uint64_t)k * N;
+        if (st >= 1 && !leaves && dat) {
+            uint32_t *d = dat + leaf0 * HH_BKT;
+            for (uint64_t q = tid; q < words; q += CONSUMERS) d[q] = 0;
+        }
+        const uint32_t nA = leaves ? U1 : 0, nB = nA + (leaves ? H1 : 0), nC = nB + (has_tree ? TU : 0), nD = nC + (leaves ? HT : 0),
+                       nE = nD + (leaves ? U2 : 0);
+        const bool negate = leaves && ((hdr[L.key_id] != 0) != (so.flip != 0));
+        uint32_t *sk = leaves && sk_base ? sk_base + (key_index(k) / so.group_size) * words : nullptr;
+        uint32_t oc0 = 0, oc1 = 0;
+        B128 oc = {{0, 0, 0, 0}};
+        if (leaves) {
+            q_wait(&qs[Q_TREE + lb], TU);                 // (done a stage ago, all but the first time)
+            oc0 = ldb32(hdr + L.oc + 1024); oc1 = ldb32(hdr + L.oc + 1028);
+            oc = ldb128(hdr + L.oc + 16 * lane);
+        }
+        uint32_t acc[4] = {0, 0, 0, 0}, t0 = 0, t1 = 0;
+        // the next unit's number is asked for before this one's work and arrives under it
+        auto grab = [&]() { uint32_t v = 0; if (lane == 0) v = atomicAdd(&qs[Q_WORK + b], 1u); return v; };
+        // ---- per-leaf pieces that occupy one lane each:
+        //  hash: tilde_pi = mmo_hash2to4(seed, x) with x = IntModN::zero() at EVERY leaf (IntModN::one() has val 0,
+        //    common/src/group.rs:448-453, so `x.add(&GIn::one())` never moves), corrected by cs when lsb(seed) = 1;
+        //  else: sign_data and ctr of the converted bucket = the first 8 bytes of counter seed+64.
+        auto leaf_unit = [&](uint32_t x, bool hash) {
+            if (x >= N) return;
+            const uint4 sd = seeds[x];
+            const uint32_t m = 0u - (sd.x & 1);
+            B128 cc = {{sd.x, sd.y, sd.z, sd.w}};
+            if (hash) {
+                const B128 s1 = mmo<NT>(T, rk0, cc);
+                const B128 s3 = mmo<NT>(T, rk0, s1);
+                const uint8_t *cs = hdr + L.cs;
+                uint4 *o = tpc + (leaf0 + x) * 4;
+                B128 q = ldb128(cs);
+                o[0] = make_uint4(tab->cx[0][0] ^ (q.w[0] & m), tab->cx[0][1] ^ (q.w[1] & m), tab->cx[0][2] ^ (q.w[2] & m), tab->cx[0][3] ^ (q.w[3] & m));
+                q = ldb128(cs + 16);
+                o[1] = make_uint4(s1.w[0] ^ (q.w[0] & m), s1.w[1] ^ (q.w[1] & m), s1.w[2] ^ (q.w[2] & m), s1.w[3] ^ (q.w[3] & m));
+                q = ldb128(cs + 32);
+                o[2] = make_uint4(tab->cx[0][4] ^ (q.w[0] & m), tab->cx[0][5] ^ (q.w[1] & m), tab->cx[0][6] ^ (q.w[2] & m), tab->cx[0][7] ^ (q.w[3] & m));
+                q = ldb128(cs + 48);
+                o[3] = make_uint4(s3.w[0] ^ (q.w[0] & m), s3.w[1] ^ (q.w[1] & m), s3.w[2] ^ (q.w[2] & m), s3.w[3] ^ (q.w[3] & m));
+            } else {
+                ctr_add(cc, 64);
+                const B128 o = mmo<NT>(T, rk0, cc);
+                uint32_t a = o.w[0] + (oc0 & m), bb = o.w[1] + (oc1 & m);
+                if (negate) { a = 0u - a; bb = 0u - bb; }
+                if (dat) *reinterpret_cast<uint2 *>(dat + (leaf0 + x) * HH_BKT + 256) = make_uint2(a, bb);
+                if (sk) { sk_add(sk + (uint64_t)x * HH_BKT + 256, a); sk_add(sk + (uint64_t)x * HH_BKT + 257, bb); }
+                t0 += a; t1 += bb;
+            }
+        };
+        // ---- convert::<Bucket<u32>>: 1032 bytes = counters seed+0 .. seed+64 (the last half used, above); leaves 2v and
+        // 2v + 1 together: 32 table reads in flight per round instead of 16 keep the LDS queue fed; the sum over leaves
+        // stays in registers
+        auto pair_unit = [&](uint32_t v) {
+            const uint32_t x = 2 * v, x1 = x + 1 < N ? x + 1 : x;    // N = 1: the leaf is computed twice, stored once
+            const uint4 sa = seeds[x], sb = seeds[x1];
+            B128 ca = {{sa.x, sa.y, sa.z, sa.w}}, cb = {{sb.x, sb.y, sb.z, sb.w}};
+            ctr_add(ca, lane); ctr_add(cb, lane);
+            B128 oa, ob;
+            mmo2<NT>(T, rk0, ca, cb, oa, ob);
+            const uint32_t ma = 0u - (sa.x & 1), mb = 0u - (sb.x & 1);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                oa.w[q] += oc.w[q] & ma; ob.w[q] += oc.w[q] & mb;
+                if (negate) { oa.w[q] = 0u - oa.w[q]; ob.w[q] = 0u - ob.w[q]; }
+                acc[q] += oa.w[q];
+                if (x1 != x) acc[q] += ob.w[q];
+            }
+            if (dat) {
+                uint2 *d = reinterpret_cast<uint2 *>(dat + (leaf0 + x) * HH_BKT + 4 * lane);  // 8-byte aligned only
+                d[0] = make_uint2(oa.w[0], oa.w[1]);
+                d[1] = make_uint2(oa.w[2], oa.w[3]);
+                if (x1 != x) {
+                    d = reinterpret_cast<uint2 *>(dat + (leaf0 + x1) * HH_BKT + 4 * lane);
+                    d[0] = make_uint2(ob.w[0], ob.w[1]);
+                    d[1] = make_uint2(ob.w[2], ob.w[3]);
+                }
+            }
+            if (sk) {
+                uint32_t *pa = sk + (uint64_t)x * HH_BKT + 4 * lane, *pb = sk + (uint64_t)x1 * HH_BKT + 4 * lane;
+#pragma unroll
+                for (int q = 0; q < 4; q++) sk_add(pa + q, oa.w[q]);
+                if (x1 != x) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) sk_add(pb + q, ob.w[q]);
+                }
+            }
+        };
+        // ---- the last SP levels of key chain st's tree under 64 of the producer's nodes: lane = node, its 2^SP leaves in
+        // registers (PrgSeed::expand_direction, common/src/prg.rs:133-174; the two children of a node are one mmo2)
+        auto tree_unit = [&](uint32_t j) {
+            const uint32_t h1 = st % 3;
+            const uint8_t *hdr1 = hdr_b + h1 * HDR_BYTES;
+            const uint32_t p = 64 * j + lane;
+            if (okf[h1] && p < NP) {
+                B128 nd[1u << HH_SPLIT];
+                uint32_t tb[1u << HH_SPLIT];
+                const uint4 s0 = nodes_b[h1 * NP + p];
+                nd[0] = B128{{s0.x, s0.y, s0.z, s0.w}};
+                tb[0] = cbits_b[h1 * NP + p];
+#pragma unroll
+                for (uint32_t l = 0; l < HH_SPLIT; l++) {
+                    if (l < SP) {
+                        const uint8_t *cwp = hdr1 + L.cw + 18 * (depth - SP + l);
+                        const B128 cw = ldb128(cwp);
+                        const uint32_t cb0 = cwp[16], cb1 = cwp[17];
+#pragma unroll
+                        for (int q = (1 << l) - 1; q >= 0; q--) {
+                            const B128 s = nd[q];
+                            const uint32_t bit = tb[q];
+                            uint32_t bl = (s.w[0] & 1) == 0, br = (s.w[0] & 2) == 0;
+                            B128 c0 = {{s.w[0] & ~3u, s.w[1], s.w[2], s.w[3]}}, c1 = c0;
+                            ctr_add(c1, 1);
+                            B128 left, right;
+                            mmo2<NT>(T, rk0, c0, c1, left, right);
+                            const uint32_t mk = 0u - bit;
+#pragma unroll
+                            for (int w = 0; w < 4; w++) { left.w[w] ^= cw.w[w] & mk; right.w[w] ^= cw.w[w] & mk; }
+                            bl ^= cb0 & bit; br ^= cb1 & bit;
+                            nd[2 * q] = left; nd[2 * q + 1] = right;
+                            tb[2 * q] = bl; tb[2 * q + 1] = br;
+                        }
+                    }
+                }
+                uint4 *out = seeds_b + (st & 1) * N + ((uint64_t)p << SP);
+#pragma unroll
+                for (uint32_t q = 0; q < (1u << HH_SPLIT); q++)
+                    if (q < (1u << SP)) out[q] = make_uint4(nd[q].w[0], nd[q].w[1], nd[q].w[2], nd[q].w[3]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) atomicAdd(&qs[Q_TREE + (st & 1)], 1u);
+        };
+
+        uint32_t u = __builtin_amdgcn_readfirstlane(grab());
+#pragma unroll 1
+        while (u < nA) { const uint32_t un = grab(); leaf_unit(64 * u + lane, true); u = __builtin_amdgcn_readfirstlane(un); }
+#pragma unroll 1
+        while (u < nB) { const uint32_t un = grab(); pair_unit(u - nA); u = __builtin_amdgcn_readfirstlane(un); }
+        if (u < nC) {
+            // the producer has published key chain st, and the leaf buffer's last readers (stage st - 1) have left
+            q_wait(&qs[Q_READY], st + 1);
+            if (st >= 2) q_wait(&qs[Q_LEFT], st);
+#pragma unroll 1
+            while (u < nC) { const uint32_t un = grab(); tree_unit(u - nB); u = __builtin_amdgcn_readfirstlane(un); }
+        }
+#pragma unroll 1
+        while (u < nD) { const uint32_t un = grab(); pair_unit(H1 + u - nC); u = __builtin_amdgcn_readfirstlane(un); }
+#pragma unroll 1
+        while (u < nE) { const uint32_t un = grab(); leaf_unit(64 * (u - nD) + lane, false); u = __builtin_amdgcn_readfirstlane(un); }
+        if (leaves) {
+            if (t0 | t1) { atomicAdd(&red[256], t0); atomicAdd(&red[257], t1); }
+#pragma unroll
+            for (int q = 0; q < 4; q++) atomicAdd(&red[4 * lane + q], acc[q]);
+        }
+        // leave the stage; the last wavefront out writes the sums and hands the buffers back
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        uint32_t dn = 0;
+        if (lane == 0) dn = atomicAdd(&qs[Q_LEFT_N + b], 1u);
+        dn = __builtin_amdgcn_readfirstlane(dn);
+        if (dn == CONSUMERS / 64 - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (st >= 1) {
+                for (uint32_t q = lane; q < HH_BKT; q += 64) { if (buckg) buckg[(uint64_t)k * HH_BKT + q] = red[q]; red[q] = 0; }
+                if (lane == 0) qs[Q_TREE + lb] = 0;
+            }
+            if (lane == 0) { qs[Q_WORK + b] = 0; qs[Q_LEFT_N + b] = 0; }
+            post(&qs[Q_LEFT], st + 1);
+        }
     }
 }
 
@@ -681,7 +800,8 @@ __global__ __launch_bounds__(64) void k_hh_final(const uint8_t *__restrict__ key
 static int hh_main_tables(uint32_t depth) { return depth <= 9 ? 4 : 2; }
 size_t hh_main_lds_bytes(uint32_t depth) {
     const size_t N = (size_t)1 << depth;
-    return 4 * (size_t)T_WORDS * hh_main_tables(depth) + 2 * 16 * N + 2 * HDR_BYTES + 4 * 524 + N + 16;
+    const size_t NP = N >> hh_split(depth);
+    return 4 * (size_t)T_WORDS * hh_main_tables(depth) + 2 * 16 * N + 3 * 16 * NP + 3 * HDR_BYTES + 4 * (524 + Q_WORDS) + 16 + 3 * NP + 16;
 }
 
 int launch_hh_main(const uint8_t *d_keys, uint64_t stride, uint32_t n, uint32_t depth, const HhTables *d_tab, const HhWork &w,
