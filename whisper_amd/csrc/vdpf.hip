@@ -715,16 +715,22 @@ __global__ __launch_bounds__(1024) void k_hh_chain(const uint8_t *__restrict__ k
 //   A  bytes of the folded bucket (258 u32, little endian)                 17 blocks
 //   B  bytes of the support sums (257 u32)                                 17 blocks
 //   C  the proof string: hex(main) | 257 x hex(support) | hex(A) | hex(B)  260 blocks + padding
+// A lane pair per key chain: the odd lane hashes A and B while the even lane is on the first 34 blocks of C (one copy of
+// the compression, the message words chosen per lane), hands the two digests over, and the even lane finishes C: 261
+// compressions in sequence instead of 295.
 __global__ __launch_bounds__(64) void k_hh_final(const uint8_t *__restrict__ keys, uint64_t stride, uint32_t n, uint32_t depth,
                                                  const uint32_t *__restrict__ proofblk, const uint32_t *__restrict__ supd,
                                                  const uint32_t *__restrict__ buckg, uint8_t *__restrict__ tags,
                                                  const int32_t *__restrict__ status) {
-    const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    const uint64_t t = (uint64_t)blockIdx.x * 64 + threadIdx.x, i = t >> 1;
+    const bool odd = t & 1;
     if (i >= n) return;
     uint32_t *tag = reinterpret_cast<uint32_t *>(tags + 64 * i);
     if (status[i] != 0) {
+        if (!odd) {
 #pragma unroll
-        for (int k = 0; k < 16; k++) tag[k] = 0;
+            for (int k = 0; k < 16; k++) tag[k] = 0;
+        }
         return;
     }
     const HhLayout L(depth);
@@ -732,31 +738,47 @@ __global__ __launch_bounds__(64) void k_hh_final(const uint8_t *__restrict__ key
     const uint32_t *bk = buckg + i * HH_BKT, *sd = supd + i * HH_SUPPORT * 2, *pb = proofblk + i * (HH_SUPPORT + 1) * 16;
     uint32_t h[8], hexA[16], hexB[16], w[16];
     sha_init(h);
+    // message C: 258 ready-made blocks (four 16-byte loads each, the next block's in flight under the compression),
+    // then hex(A), hex(B) and the padding block
+    const uint4 *pq = reinterpret_cast<const uint4 *>(pb);
+    uint4 nx[4] = {pq[0], pq[1], pq[2], pq[3]};
+    auto c_block = [&](uint32_t b) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) { w[4 * q] = nx[q].x; w[4 * q + 1] = nx[q].y; w[4 * q + 2] = nx[q].z; w[4 * q + 3] = nx[q].w; }
+        if (b + 1 < HH_SUPPORT + 1) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) nx[q] = pq[4 * (b + 1) + q];
+        }
+    };
 #pragma unroll 1
     for (uint32_t blk = 0; blk < 34; blk++) {
-        const bool isA = blk < 17;
-        const uint32_t b = isA ? blk : blk - 17, words = isA ? HH_BKT : HH_SUPPORT;
+        if (odd) {
+            const bool isA = blk < 17;
+            const uint32_t b = isA ? blk : blk - 17, words = isA ? HH_BKT : HH_SUPPORT;
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const uint32_t e = 16 * b + k;
-            uint32_t v = 0;
-            if (e < words) {
-                const uint32_t d0 = e < HH_SUPPORT ? sd[2 * e] : 0, d1 = e < HH_SUPPORT ? sd[2 * e + 1] : 0;
-                if (isA) {
-                    // buck -= (right - left) per support key; key 1 also takes 1 off ctr and negates (protocol.rs:99-126)
-                    v = bk[e] - (d1 - d0);
-                    if (kid) { if (e == HH_BKT - 1) v -= 1; v = 0u - v; }
-                } else {
-                    v = d0 + d1;                      // must be 1 across the two servers (protocol.rs:104-108, 143-148)
-                    if (kid) v = 0u - (v - 1);
-                }
-                v = __builtin_bswap32(v);             // little-endian bytes of the u32 as a big-endian message word
-            } else if (e == words) v = 0x80000000u;
-            else if (e == 271) v = words * 32;        // message length in bits
-            w[k] = v;
+            for (int k = 0; k < 16; k++) {
+                const uint32_t e = 16 * b + k;
+                uint32_t v = 0;
+                if (e < words) {
+                    const uint32_t d0 = e < HH_SUPPORT ? sd[2 * e] : 0, d1 = e < HH_SUPPORT ? sd[2 * e + 1] : 0;
+                    if (isA) {
+                        // buck -= (right - left) per support key; key 1 also takes 1 off ctr and negates (protocol.rs:99-126)
+                        v = bk[e] - (d1 - d0);
+                        if (kid) { if (e == HH_BKT - 1) v -= 1; v = 0u - v; }
+                    } else {
+                        v = d0 + d1;                      // must be 1 across the two servers (protocol.rs:104-108, 143-148)
+                        if (kid) v = 0u - (v - 1);
+                    }
+                    v = __builtin_bswap32(v);             // little-endian bytes of the u32 as a big-endian message word
+                } else if (e == words) v = 0x80000000u;
+                else if (e == 271) v = words * 32;        // message length in bits
+                w[k] = v;
+            }
+        } else {
+            c_block(blk);
         }
         sha_compress(h, w);
-        if (blk == 16 || blk == 33) {
+        if (odd && (blk == 16 || blk == 33)) {
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 uint32_t a, b2;
@@ -766,19 +788,17 @@ __global__ __launch_bounds__(64) void k_hh_final(const uint8_t *__restrict__ key
             sha_init(h);
         }
     }
-    // message C: 258 ready-made blocks (four 16-byte loads each, the next block's in flight under the compression),
-    // then hex(A), hex(B) and the padding block
-    const uint4 *pq = reinterpret_cast<const uint4 *>(pb);
-    uint4 nx[4] = {pq[0], pq[1], pq[2], pq[3]};
+    // the digests cross to the even lane (the pair sits in one quad: a DPP swap of neighbours)
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        hexA[k] = (uint32_t)__builtin_amdgcn_mov_dpp((int)hexA[k], 0xB1, 0xF, 0xF, true);     // quad_perm [1, 0, 3, 2]
+        hexB[k] = (uint32_t)__builtin_amdgcn_mov_dpp((int)hexB[k], 0xB1, 0xF, 0xF, true);
+    }
+    if (odd) return;
 #pragma unroll 1
-    for (uint32_t b = 0; b < HH_SUPPORT + 4; b++) {
+    for (uint32_t b = 34; b < HH_SUPPORT + 4; b++) {
         if (b < HH_SUPPORT + 1) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) { w[4 * q] = nx[q].x; w[4 * q + 1] = nx[q].y; w[4 * q + 2] = nx[q].z; w[4 * q + 3] = nx[q].w; }
-            if (b + 1 < HH_SUPPORT + 1) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) nx[q] = pq[4 * (b + 1) + q];
-            }
+            c_block(b);
         } else {
 #pragma unroll
             for (int k = 0; k < 16; k++)
@@ -849,7 +869,7 @@ int launch_hh_chain(const uint8_t *d_keys, uint64_t stride, uint32_t n, uint32_t
 }
 int launch_hh_final(const uint8_t *d_keys, uint64_t stride, uint32_t n, uint32_t depth, const HhWork &w, uint8_t *d_tags,
                     const int32_t *d_status, hipStream_t stream) {
-    hipLaunchKernelGGL(k_hh_final, dim3((n + 63) / 64), dim3(64), 0, stream, d_keys, stride, n, depth, w.proofblk, w.supd, w.buckg, d_tags,
+    hipLaunchKernelGGL(k_hh_final, dim3((n + 31) / 32), dim3(64), 0, stream, d_keys, stride, n, depth, w.proofblk, w.supd, w.buckg, d_tags,
                        d_status);
     return (int)hipGetLastError();
 }
