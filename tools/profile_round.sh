@@ -1,7 +1,8 @@
 #!/bin/bash
 # Evidence for profiles/: kernel-trace stats, HBM traffic counters (separate passes), the Keccak ceiling, and the default bench
 # line (CPU baseline + the `extra` lines of the other configurations).  The small workloads get their own kernel stats and
-# traffic passes.  Usage on the GPU box: tools/profile_round.sh <tag>   (writes gpurun_out/<tag>_*)
+# traffic passes.  Usage on the GPU box: tools/profile_round.sh <tag> [hh]  (writes gpurun_out/<tag>_*; `hh`: only the kernel
+# stats of the two heavy-hitter workloads)
 tag=${1:-rX}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out; mkdir -p $O
@@ -19,6 +20,10 @@ pmc() {     # pmc <suffix> <workload> <reports> <bench args...>: FETCH_SIZE and 
   done
   python3 $R/tools/pmc_traffic.py $O/${tag}_pmc_FETCH_SIZE$sfx $O/${tag}_pmc_WRITE_SIZE$sfx "$tag" $wl reports_per_gpu $n $O/${tag}_pmc_traffic.json > $O/${tag}_pmc_traffic.tmp && mv $O/${tag}_pmc_traffic.tmp $O/${tag}_pmc_traffic.json
 }
+if [ "$2" = hh ]; then
+  for w in hh_t0.01 hh_t0.001; do stats _$w --workload $w || exit 1; done
+  exit 0
+fi
 rm -f $O/${tag}_pmc_traffic.json
 stats "" || exit 1
 pmc "" sumvec_large 125000 || exit 1

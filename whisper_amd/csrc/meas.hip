@@ -16,6 +16,11 @@
 // 2^-59 each): then the absorbed stream is the squeezed stream, 42 bytes (the absorber's prefix)
 // out of phase, and every word index is static.  A pair that sees a rejected chunk puts its report
 // on the dirty list; those reports are redone by the general path (k_expand + mode 1 here).
+//
+// The two lanes of a pair are two THREADS to the compiler.  The DPP exchange (a convergent operation) is what keeps their
+// regions in program order; a variant that handed the words over through memory -- `if (even) { stores } fence;
+// if (!even) { loads }` -- was compiled to `if (!even) { fence; loads } else { stores; fence }`, legal per thread, and read the
+// row before it was written until a __builtin_amdgcn_wave_barrier() sat between the regions (profiles/r3_meas_readback.txt).
 #include <hip/hip_runtime.h>
 #include "keccak.hpp"
 #include "prio3_dev.hpp"
