@@ -28,14 +28,16 @@ enum { WH_SUMVEC = 0, WH_HISTOGRAM = 1, WH_AVERAGE = 2 };
 
 /* Instance parameters: the arguments of Prio3::new_sum_vec_256 / new_histogram_256 /
  * new_average_256 (vdaf/prio3.rs:150-165, 300-313, 360-380) as the servers call them
- * (server-batch-prio3/src/main.rs:249-257).  The batched path needs num_aggregators == 2 (Alice and
- * Bob); the draft-07 prepare_init path takes 2..255. */
+ * (server-batch-prio3/src/main.rs:249-257).  The servers run two aggregators (Alice and Bob); the batched path, like
+ * Prio3::prepare_batched (prio3.rs:2843-2855; its own test runs three, :3077-3085), and the draft-07 prepare_init path
+ * take 2..255.  Aggregator 0 is the Leader (explicit shares), 1.. are Helpers (seeds).  The GPU sharder
+ * (wh_client_shard_many_gpu) is built for two. */
 typedef struct {
     uint32_t circuit;         /* WH_SUMVEC | WH_HISTOGRAM | WH_AVERAGE */
     uint32_t bits;            /* SumVec: 16 in the servers; Average: AVG_BITS = 64 */
     uint32_t len;             /* SumVec vec_size / Histogram length */
     uint32_t chunk;           /* chunk_size */
-    uint32_t num_aggregators; /* 2 */
+    uint32_t num_aggregators; /* 2 in the servers */
     uint32_t alg_id;          /* 0 = the circuit's own algorithm id (types.rs:577,383,242); otherwise the
                                * `Type::ID` to bind into every XOF, e.g. 1 to run Average's circuit as
                                * draft-07 Prio3Sum (types.rs:142-208) */
@@ -416,15 +418,16 @@ int32_t wh_ctx_kernel_times(wh_ctx *ctx, double *ms, uint64_t *launches, int32_t
 
 /* ---- client side (CPU): input generator ---- */
 /* replaces: Prio3::shard_batched + VdafBatchedKey::get_encoded as client-batch-prio3 uses them
- * (client-batch-prio3/src/main.rs:67-153; vdaf/prio3.rs:537-991).  `rand` is the 144-byte
- * random string shard_with_random_new consumes; writes both encoded reports. */
+ * (client-batch-prio3/src/main.rs:67-153; vdaf/prio3.rs:537-991).  `rand` is the random string
+ * shard_with_random_new consumes, 16 (5 num_aggregators - 1) bytes (144 for Alice and Bob); writes the Leader's
+ * encoded report and the num_aggregators - 1 Helpers' (helper_report_len bytes each, aggregator 1 first). */
 int32_t wh_client_shard_batched(const wh_prio3_params *params, const uint64_t *measurement,
-                                const uint8_t nonce[16], const uint8_t rand[144],
+                                const uint8_t nonce[16], const uint8_t *rand,
                                 const uint8_t client_id_be[16], uint8_t *leader_report,
                                 uint8_t *helper_report);
 /* many reports on `nthreads` host threads; measurements[n][meas_words], nonces[n][16],
- * rands[n][144], client ids = first_client_id + i; reports written at leader_reports + i*leader_len
- * and helper_reports + i*helper_len */
+ * rands[n][16 (5 num_aggregators - 1)], client ids = first_client_id + i; reports written at leader_reports + i*leader_len
+ * and helper_reports + (i*(num_aggregators - 1) + a - 1)*helper_len */
 int32_t wh_client_shard_many(const wh_prio3_params *params, const uint64_t *measurements, uint32_t meas_words,
                              const uint8_t *nonces, const uint8_t *rands, uint64_t first_client_id, uint64_t n,
                              uint32_t nthreads, uint8_t *leader_reports, uint8_t *helper_reports);

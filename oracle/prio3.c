@@ -169,11 +169,16 @@ static void put_be64(uint8_t *b, uint64_t v) { for (int i = 0; i < 8; i++) b[i] 
 int wo_prio3_shard_batched(const wo_params *p, const uint64_t *meas, const uint8_t nonce[16], const uint8_t *rand,
                            const uint8_t client_id_be[16], uint8_t *leader_report, uint8_t *helper_report) {
     wo_sizes sz; int rc = wo_sizes_of(p, &sz); if (rc) return rc;
-    if (p->num_aggregators != 2) return WO_ERR_PARAM; /* the servers are Alice and Bob */
-    /* random_seeds order, prio3.rs:579-581,589,647,705,753,826,883 */
-    const uint8_t *h_meas_seed = rand, *h_proof_seed[2] = {rand + 16, rand + 32}, *h_jr_blind = rand + 48,
-                  *l_jr_blind = rand + 64, *prove_seed[2] = {rand + 80, rand + 96}, *h_qr_blind = rand + 112,
-                  *l_qr_blind = rand + 128;
+    /* Alice and Bob are two aggregators (server-batch-prio3); shard_batched itself is generic in their number and its own
+     * test runs three (prio3.rs:3077-3085).  rand: 16 (5 na - 1) bytes (random_size_double_field, prio3.rs:515-533);
+     * helper_report: na - 1 reports of helper_report_len bytes, aggregator 1 first. */
+    const uint32_t na = p->num_aggregators, nh = na - 1;
+    /* random_seeds order, prio3.rs:579-581,589 (per Helper), 647, 705, 753, 826 (per Helper), 883 */
+    const uint8_t *l_jr_blind = rand + 64 * (size_t)nh, *prove_seed[2] = {l_jr_blind + 16, l_jr_blind + 32},
+                  *h_qr_blinds = l_jr_blind + 48, *l_qr_blind = h_qr_blinds + 16 * (size_t)nh;
+#define H_MEAS_SEED(a) (rand + 64 * (size_t)((a) - 1))
+#define H_PROOF_SEED(a, t) (rand + 64 * (size_t)((a) - 1) + 16 + 16 * (t))
+#define H_JR_BLIND(a) (rand + 64 * (size_t)((a) - 1) + 48)
     uint32_t njr = 2 * sz.joint_rand_len;
     u128 *enc = wo_alloc(sz.input_len * sizeof(u128)), *h_meas = wo_alloc(sz.input_len * sizeof(u128));
     u128 *l_meas = wo_alloc(sz.input_len * sizeof(u128));
@@ -183,34 +188,46 @@ int wo_prio3_shard_batched(const wo_params *p, const uint64_t *meas, const uint8
         proof[t] = wo_alloc(sz.proof_len * sizeof(u128)); l_proof[t] = wo_alloc(sz.proof_len * sizeof(u128));
         h_proof[t] = wo_alloc(sz.proof_len * sizeof(u128)); pub_proof[t] = wo_alloc(sz.verifier_len * sizeof(u128));
     }
-    uint8_t one = 1, jr_parts[32], qr_parts[32], seed[16];
+    uint8_t jr_parts[16 * 256], qr_parts[16 * 256], seed[16];
     u128 jr_fused[4], qr_fused[2];
     rc = flp_encode(p, meas, enc);
     if (rc) goto done;
-    expand_usage(p, h_meas_seed, DST_MEAS, &one, 1, h_meas, sz.input_len);
-    for (uint32_t i = 0; i < sz.input_len; i++) l_meas[i] = f_sub(enc[i], h_meas[i]);
-    joint_rand_part(p, h_jr_blind, 1, nonce, h_meas, sz.input_len, jr_parts + 16);
+    memcpy(l_meas, enc, sz.input_len * sizeof(u128));
+    for (uint32_t a = 1; a < na; a++) {                                      /* prio3.rs:574-638 */
+        uint8_t id = (uint8_t)a;
+        expand_usage(p, H_MEAS_SEED(a), DST_MEAS, &id, 1, h_meas, sz.input_len);
+        for (uint32_t i = 0; i < sz.input_len; i++) l_meas[i] = f_sub(l_meas[i], h_meas[i]);
+        joint_rand_part(p, H_JR_BLIND(a), id, nonce, h_meas, sz.input_len, jr_parts + 16 * a);
+    }
     joint_rand_part(p, l_jr_blind, 0, nonce, l_meas, sz.input_len, jr_parts);
-    derive_joint_rand_seed(p, jr_parts, 2, seed);
+    derive_joint_rand_seed(p, jr_parts, na, seed);
     expand_usage(p, seed, DST_JOINT_RAND, NULL, 0, jr_fused, njr);           /* prio3.rs:675-688 */
     for (int t = 0; t < 2; t++) {                                            /* prio3.rs:703-782 */
         expand_usage(p, prove_seed[t], DST_PROVE_RAND, NULL, 0, prove_rand, sz.prove_rand_len);
         if ((rc = flp_prove(p, enc, prove_rand, jr_fused + t * sz.joint_rand_len, proof[t]))) goto done;
-        expand_usage(p, h_proof_seed[t], DST_PROOF, &one, 1, h_proof[t], sz.proof_len);
-        for (uint32_t i = 0; i < sz.proof_len; i++) l_proof[t][i] = f_sub(proof[t][i], h_proof[t][i]);
+        memcpy(l_proof[t], proof[t], sz.proof_len * sizeof(u128));
+        for (uint32_t a = 1; a < na; a++) {
+            uint8_t id = (uint8_t)a;
+            expand_usage(p, H_PROOF_SEED(a, t), DST_PROOF, &id, 1, h_proof[t], sz.proof_len);
+            for (uint32_t i = 0; i < sz.proof_len; i++) l_proof[t][i] = f_sub(l_proof[t][i], h_proof[t][i]);
+        }
     }
-    query_rand_part(p, h_qr_blind, jr_fused, njr, h_proof[0], h_proof[1], sz.proof_len, qr_parts + 16);
+    for (uint32_t a = 1; a < na; a++) {                                      /* prio3.rs:806-874 */
+        uint8_t id = (uint8_t)a;
+        for (int t = 0; t < 2; t++) expand_usage(p, H_PROOF_SEED(a, t), DST_PROOF, &id, 1, h_proof[t], sz.proof_len);
+        query_rand_part(p, h_qr_blinds + 16 * (size_t)(a - 1), jr_fused, njr, h_proof[0], h_proof[1], sz.proof_len, qr_parts + 16 * a);
+    }
     query_rand_part(p, l_qr_blind, jr_fused, njr, l_proof[0], l_proof[1], sz.proof_len, qr_parts);
-    derive_joint_rand_seed(p, qr_parts, 2, seed);                            /* dst 6 again, prio3.rs:933 */
+    derive_joint_rand_seed(p, qr_parts, na, seed);                           /* dst 6 again, prio3.rs:933 */
     expand_usage(p, seed, DST_QUERY_RAND, NULL, 0, qr_fused, 2);
     for (int t = 0; t < 2; t++)                                              /* prio3.rs:951-969, num_shares = 1 */
         if ((rc = flp_query(p, enc, proof[t], qr_fused + t, jr_fused + t * sz.joint_rand_len, 1, pub_proof[t]))) goto done;
 
     /* VdafBatchedKey::encode, vdaf.rs:148-162 */
-    for (int a = 0; a < 2; a++) {
-        uint8_t *o = a ? helper_report : leader_report;
+    for (uint32_t a = 0; a < na; a++) {
+        uint8_t *o = a ? helper_report + (size_t)(a - 1) * sz.helper_report_len : leader_report;
         memcpy(o, client_id_be, 16); o += 16;
-        memcpy(o, jr_parts, 32); o += 32;
+        memcpy(o, jr_parts, 16 * (size_t)na); o += 16 * (size_t)na;
         *o++ = (uint8_t)a;
         if (a == 0) {
             enc_vec(l_meas, sz.input_len, o); o += 16 * (size_t)sz.input_len;
@@ -218,16 +235,19 @@ int wo_prio3_shard_batched(const wo_params *p, const uint64_t *meas, const uint8
             memcpy(o, l_jr_blind, 16); o += 16;
             enc_vec(l_proof[1], sz.proof_len, o); o += 16 * (size_t)sz.proof_len;
         } else {
-            memcpy(o, h_meas_seed, 16); memcpy(o + 16, h_proof_seed[0], 16); memcpy(o + 32, h_jr_blind, 16);
-            memcpy(o + 48, h_proof_seed[1], 16); o += 64;
+            memcpy(o, H_MEAS_SEED(a), 16); memcpy(o + 16, H_PROOF_SEED(a, 0), 16); memcpy(o + 32, H_JR_BLIND(a), 16);
+            memcpy(o + 48, H_PROOF_SEED(a, 1), 16); o += 64;
         }
-        memcpy(o, qr_parts, 32); o += 32;
+        memcpy(o, qr_parts, 16 * (size_t)na); o += 16 * (size_t)na;
         put_be64(o, sz.verifier_len); o += 8;   /* num_queries, client-batch-prio3/src/main.rs:111-112 */
         enc_vec(pub_proof[0], sz.verifier_len, o); o += 16 * (size_t)sz.verifier_len;
         enc_vec(pub_proof[1], sz.verifier_len, o); o += 16 * (size_t)sz.verifier_len;
-        memcpy(o, a ? h_qr_blind : l_qr_blind, 16); o += 16;
+        memcpy(o, a ? h_qr_blinds + 16 * (size_t)(a - 1) : l_qr_blind, 16); o += 16;
         memcpy(o, nonce, 16);
     }
+#undef H_MEAS_SEED
+#undef H_PROOF_SEED
+#undef H_JR_BLIND
 done:
     for (int t = 0; t < 2; t++) { wo_free(proof[t]); wo_free(l_proof[t]); wo_free(h_proof[t]); wo_free(pub_proof[t]); }
     wo_free(enc); wo_free(h_meas); wo_free(l_meas); wo_free(prove_rand);
@@ -238,7 +258,8 @@ done:
 int wo_prio3_prepare_encoded_key(const wo_params *p, const uint8_t verify_key[16], const uint8_t *rep, size_t rep_len,
                                  uint8_t tag_out[16], uint8_t testing_id[16], uint8_t *out_share) {
     wo_sizes sz; int rc = wo_sizes_of(p, &sz); if (rc) return rc;
-    if (p->num_aggregators != 2) return WO_ERR_PARAM;
+    const uint32_t na = p->num_aggregators;   /* the servers run 2; prepare_batched is generic (prio3.rs:2843-2855) */
+    const size_t psb = 16 * (size_t)na;       /* bytes of a public share: one part per aggregator */
     uint32_t njr = 2 * sz.joint_rand_len;
     u128 *meas = wo_alloc(sz.input_len * sizeof(u128)), *out = wo_alloc(sz.output_len * sizeof(u128));
     u128 *proof[2] = {wo_alloc(sz.proof_len * sizeof(u128)), wo_alloc(sz.proof_len * sizeof(u128))};
@@ -252,14 +273,14 @@ int wo_prio3_prepare_encoded_key(const wo_params *p, const uint8_t verify_key[16
      * cause.  Structure is checked before values so that the code does not depend on the
      * decoder's read order: SHORT / AGG_ID / NUM_QUERIES first, then MODULUS. --- */
     const size_t share_len[2] = {16 * (size_t)(sz.input_len + 2 * sz.proof_len) + 16, 64};
-    if (rep_len < 49) { rc = WO_ERR_SHORT; goto done; }
+    if (rep_len < 17 + psb) { rc = WO_ERR_SHORT; goto done; }
     const uint8_t *client_id = rep, *ps_parts = rep + 16;
-    uint8_t agg_id = rep[48];
-    if (agg_id >= 2) { rc = WO_ERR_AGG_ID; goto done; }   /* role_try_from via decode, prio3.rs:1780-1782 */
-    size_t off = 49, share_off = 49;
-    off += share_len[agg_id];
-    if (rep_len < off + 40) { rc = WO_ERR_SHORT; goto done; }
-    const uint8_t *ps2_parts = rep + off; off += 32;
+    uint8_t agg_id = rep[16 + psb];
+    if (agg_id >= na) { rc = WO_ERR_AGG_ID; goto done; }   /* role_try_from via decode, prio3.rs:1780-1782 */
+    size_t off = 17 + psb, share_off = 17 + psb;
+    off += share_len[agg_id != 0];
+    if (rep_len < off + psb + 8) { rc = WO_ERR_SHORT; goto done; }
+    const uint8_t *ps2_parts = rep + off; off += psb;
     uint64_t num_queries = 0;
     for (int i = 0; i < 8; i++) num_queries = (num_queries << 8) | rep[off + i];
     off += 8;
@@ -294,18 +315,18 @@ int wo_prio3_prepare_encoded_key(const wo_params *p, const uint8_t verify_key[16
 
     /* --- prepare_batched --- */
     flp_truncate(p, meas, out);                                              /* prio3.rs:2496 */
-    uint8_t own_jr[16], own_qr[16], parts[32], seed[16];
+    uint8_t own_jr[16], own_qr[16], parts[16 * 256], seed[16];
     u128 jr_fused[4], qr_fused[2];
     joint_rand_part(p, jr_blind, agg_id, nonce, meas, sz.input_len, own_jr); /* :2543-2555 */
-    memcpy(parts, ps_parts, 32); memcpy(parts + 16 * agg_id, own_jr, 16);    /* :2564-2576 */
-    derive_joint_rand_seed(p, parts, 2, seed);
+    memcpy(parts, ps_parts, psb); memcpy(parts + 16 * agg_id, own_jr, 16);   /* :2564-2576 */
+    derive_joint_rand_seed(p, parts, na, seed);
     expand_usage(p, seed, DST_JOINT_RAND, NULL, 0, jr_fused, njr);           /* :2580-2585 */
     query_rand_part(p, qr_blind, jr_fused, njr, proof[0], proof[1], sz.proof_len, own_qr); /* :2610-2642 */
-    memcpy(parts, ps2_parts, 32); memcpy(parts + 16 * agg_id, own_qr, 16);
-    derive_joint_rand_seed(p, parts, 2, seed);                               /* :2665 (dst 6) */
+    memcpy(parts, ps2_parts, psb); memcpy(parts + 16 * agg_id, own_qr, 16);
+    derive_joint_rand_seed(p, parts, na, seed);                              /* :2665 (dst 6) */
     expand_usage(p, seed, DST_QUERY_RAND, NULL, 0, qr_fused, 2);             /* :2667-2672 */
     for (int t = 0; t < 2; t++)                                              /* :2687-2701 */
-        if ((rc = flp_query(p, meas, proof[t], qr_fused + t, jr_fused + t * sz.joint_rand_len, 2, ver[t]))) goto done;
+        if ((rc = flp_query(p, meas, proof[t], qr_fused + t, jr_fused + t * sz.joint_rand_len, na, ver[t]))) goto done;
 
     /* :2713-2739 -- run 1's difference is computed and dropped; run 2's is kept */
     u128 *diff = ver[1];
@@ -318,24 +339,26 @@ int wo_prio3_prepare_encoded_key(const wo_params *p, const uint8_t verify_key[16
     static const uint8_t zero[16] = {0};
     shake_t hs;
     xof_init_usage(&hs, p, zero, DST_HASH);
-    shake_absorb(&hs, ps_parts, 32);
-    shake_absorb(&hs, ps2_parts, 32);
+    shake_absorb(&hs, ps_parts, psb);
+    shake_absorb(&hs, ps2_parts, psb);
     shake_absorb(&hs, pp_bytes, 32 * (size_t)sz.verifier_len); /* canonical bytes: decode checked < p */
     xof_into_seed(&hs, seed);
     u128 hash;
     expand_usage(p, seed, DST_HASH, NULL, 0, &hash, 1);
-    u128 hash_share = agg_id == 0 ? f_neg(hash) : hash;                      /* :2844-2855 */
     /* :2859-2862 */
-    uint32_t check_count = 2 * sz.verifier_len + 2 + 2 + 1;
+    uint32_t check_count = 2 * sz.verifier_len + 2 + 2 + (na - 1);
     rlc = wo_alloc(check_count * sizeof(u128));
     expand_usage(p, verify_key, DST_RLC, nonce, 16, rlc, check_count);
-    /* :2864-2871 -- zip stops after verifier_len + 5 terms */
+    /* :2864-2871 -- zip stops after verifier_len + 4 + (na - 1) terms */
     u128 tag = 0;
     uint32_t k = 0;
     for (uint32_t i = 0; i < sz.verifier_len; i++) tag = f_add(tag, f_mul(diff[i], rlc[k++]));
     for (int i = 0; i < 2; i++) tag = f_add(tag, f_mul(decide_zero[i], rlc[k++]));
     for (int i = 0; i < 2; i++) tag = f_add(tag, f_mul(rand_diffs[i], rlc[k++]));
-    tag = f_add(tag, f_mul(hash_share, rlc[k++]));
+    for (uint32_t j = 0; j + 1 < na; j++) {                                  /* :2844-2855: Leader -H everywhere, Helper a +H at a - 1 */
+        u128 hash_share = agg_id == 0 ? f_neg(hash) : (j == (uint32_t)agg_id - 1 ? hash : 0);
+        tag = f_add(tag, f_mul(hash_share, rlc[k++]));
+    }
 
     /* prepare_encoded_key, main.rs:51-59 */
     uint8_t id_le[16];

@@ -172,8 +172,10 @@ def prio3_prepare_init(p, verify_key, agg_id, nonce, public_share, input_share):
 
 
 def prio3_shard_batched(p, meas, nonce, rand, client_id):
+    """-> (leader report, the Helpers' reports back to back: num_aggregators - 1 of helper_report_len bytes)"""
     s = sizes(p)
-    lr = _buf(s.leader_report_len); hr = _buf(s.helper_report_len)
+    assert len(rand) == 16 * (5 * p.num_aggregators - 1)
+    lr = _buf(s.leader_report_len); hr = _buf(s.helper_report_len * (p.num_aggregators - 1))
     rc = _lib.wo_prio3_shard_batched(C.byref(p), _meas(meas), _b(nonce), _b(rand), _b(int(client_id).to_bytes(16, "big")), lr, hr)
     assert rc == 0, rc
     return bytes(lr), bytes(hr)

@@ -268,3 +268,31 @@ def test_prepare_init_takes_any_batch_length_in_sub_batches():
     j = 33
     rc, want_prep, want_out = O.prio3_prepare_init(op, vk, na - 1, shards[j][0], shards[j][1], shards[j][2][na - 1])
     assert rc == 0 and split[0][na - 1][j].tobytes() == want_prep and split[2][j].tobytes() == want_out
+
+
+def test_prepare_init_batch_that_mixes_aggregator_ids():
+    """One batch with keys of all aggregator ids interleaved (a wavefront then holds lanes whose joint-rand seed sponges absorb
+    segments of different lengths, keccak.hpp: xor_word): every prepare share and out share equals the oracle's."""
+    circ, bits, ln, ch, na, n = W.SUMVEC, 3, 20, 6, 3, 200
+    p = W.Prio3Params(circ, bits, ln, ch, na)
+    op = O.params(circ, bits, ln, ch, na)
+    vk = bytes(det(b"vk-mixed", 16))
+    keys, want = [], []
+    for i in range(n):
+        nonce = bytes(det(b"mn%d" % i, 16))
+        rand = bytes(det(b"mr%d" % i, O.prio3_rand_size(op)))
+        ps, ish = O.prio3_shard(op, measurement_for(circ, bits, ln, i), nonce, rand)
+        a = (i * 7 + i // 5) % na
+        keys.append(W.Prio3.encode_vdaf_key(a, ps, ish[a], nonce))
+        rc, wp, wo = O.prio3_prepare_init(op, vk, a, nonce, ps, ish[a])
+        assert rc == 0
+        want.append((wp, wo))
+    vdaf = W.Prio3(p)
+    try:
+        prep, status = vdaf.prepare_init_encoded_keys(vk, keys)
+        outs = vdaf.out_shares()
+        assert not status.any()
+        for j in range(n):
+            assert prep[j].tobytes() == want[j][0] and outs[j].tobytes() == want[j][1], j
+    finally:
+        vdaf.close()

@@ -263,7 +263,7 @@ int32_t alloc_workspace(wh_ctx *c, uint64_t cap) {
     HIPCHK(c, hipMalloc((void **)&W.desc, cap * sizeof(RepDesc)));
     HIPCHK(c, hipMalloc((void **)&W.scal, cap * sizeof(RepScal)));
     HIPCHK(c, hipMalloc((void **)&W.weights, cap * (uint64_t)(z.calls + 1) * sizeof(F128)));
-    HIPCHK(c, hipMalloc((void **)&W.rlc, cap * (uint64_t)(z.verifier_len + 5) * sizeof(F128)));
+    HIPCHK(c, hipMalloc((void **)&W.rlc, cap * (uint64_t)(z.verifier_len + 4 + (c->params.num_aggregators - 1)) * sizeof(F128)));
     if (c->params.circuit != WH_AVERAGE) HIPCHK(c, hipMalloc((void **)&W.wlimbs, cap * (uint64_t)z.calls * 48));
     HIPCHK(c, hipMalloc((void **)&W.pows, cap * sizeof(RepPow)));
     HIPCHK(c, hipMalloc((void **)&W.hrows, cap * W.hrow_bytes));
@@ -475,12 +475,13 @@ struct PrepPlan { uint64_t vk0 = 0, vk1 = 0; QueryLaunch q{}; const SortPlan *so
 
 static int32_t prepare_begin(wh_ctx *c, const uint8_t verify_key[16], uint64_t n, uint64_t max_range, const int32_t *d_status,
                              PrepPlan &pl) {
-    if (n > 0xfffffff0ull || c->params.num_aggregators != 2) return WH_ERR_PARAM;
+    // (any number of aggregators: the servers run two, Prio3::prepare_batched is generic, prio3.rs:2843-2855)
+    if (n > 0xfffffff0ull) return WH_ERR_PARAM;
     HIPCHK(c, hipSetDevice(c->device));
     const HostSizes &z = c->z;
     int32_t rc;
     c->P.mode = 0; c->P.ver_stride = 0;
-    c->P.half = f_inv(f_small(2));
+    c->P.half = f_inv(f_small(c->params.num_aggregators));
     // allocations first (none inside the launch sequence once the context is warm)
     if ((rc = alloc_workspace(c, pick_cap(c, max_range)))) return rc;
     if ((rc = ensure(c, c->d_out_shares, c->out_cap, (n ? n : 1) * (uint64_t)z.output_len))) return rc;
@@ -877,7 +878,7 @@ int32_t wh_client_shard_many_gpu(wh_ctx *c, const uint64_t *measurements, uint32
     if (n > 0x7fffffffull) return WH_ERR_PARAM;
     const HostSizes &z = c->z;
     const wh_prio3_params &p = c->params;
-    if (p.num_aggregators != 2) return WH_ERR_PARAM;
+    if (p.num_aggregators != 2) { c->err = "shard on the GPU: two aggregators only (wh_client_shard_many takes any number)"; return WH_ERR_UNSUPPORTED; }
     if (meas_words < (p.circuit == WH_SUMVEC ? p.len : 1u)) return WH_ERR_PARAM;
     if (z.m > PROVE_MAX_M) { c->err = "shard: more than 511 gadget calls do not fit the prover's LDS"; return WH_ERR_UNSUPPORTED; }
     if (2 * z.jr_len > 4) { c->err = "shard: joint randomness longer than two elements per proof"; return WH_ERR_UNSUPPORTED; }

@@ -52,10 +52,11 @@ __device__ __forceinline__ void chain_body(const Prio3Dev &P, const Workspace &W
     if (status[i] != ST_OK) return;
     const RepDesc d = W.desc[i];
     RepScal *sc = &W.scal[i];
-    const uint8_t *agg_id = d.base + 48;
+    const uint32_t psb = 16 * P.num_aggregators;    // bytes of a public share: one part per aggregator
+    const uint8_t *agg_id = d.base + 16 + psb;
     const uint8_t *ps_parts = d.base + 16;
     const uint8_t *ps2_parts = d.tail;
-    const uint8_t *pp = d.tail + 40;
+    const uint8_t *pp = d.tail + psb + 8;
     const uint8_t *qr_blind = pp + 32ull * P.verifier_len;
     const uint8_t *nonce = qr_blind + 16;
     const uint32_t njr = 2 * P.jr_len;
@@ -89,8 +90,8 @@ __device__ __forceinline__ void chain_body(const Prio3Dev &P, const Workspace &W
         case CS_JR_SEED:        // derive_joint_rand_seed over the parts, own part at index role (prio3.rs:482-493)
         case CS_QR_SEED: {      // the same function, DST_JR_SEED included, for the query randomness (:2651-2665)
             const uint8_t *parts = stg == CS_JR_SEED ? ps_parts : ps2_parts;
-            usage = DST_JR_SEED; l1 = 16; l2 = 16;
-            if (d.role == 0) { p1 = own; p2 = parts + 16; } else { p1 = parts; p2 = own; }
+            usage = DST_JR_SEED;
+            p1 = parts; l1 = 16 * d.role; p2 = own; l2 = 16; p3 = parts + 16 * (d.role + 1); l3 = psb - 16 * (d.role + 1);
             break;
         }
         case CS_JR: usage = DST_JOINT_RAND; k0 = sd.lo; k1 = sd.hi; emit_n = njr; emit_p = reinterpret_cast<uint8_t *>(sc->jr); break;
@@ -101,12 +102,12 @@ __device__ __forceinline__ void chain_body(const Prio3Dev &P, const Workspace &W
             break;
         case CS_QR: usage = DST_QUERY_RAND; k0 = sd.lo; k1 = sd.hi; emit_n = 2; emit_p = reinterpret_cast<uint8_t *>(sc->qr); break;
         case CS_HASH:           // XOF(0, 10) . parts . parts2 . enc(pp0) . enc(pp1)
-            usage = DST_HASH; p1 = ps_parts; l1 = 32; p2 = ps2_parts; l2 = 32; p3 = pp; l3 = 32u * P.verifier_len;
+            usage = DST_HASH; p1 = ps_parts; l1 = psb; p2 = ps2_parts; l2 = psb; p3 = pp; l3 = 32u * P.verifier_len;
             break;
         case CS_HASH_ELEM: usage = DST_HASH; k0 = sd.lo; k1 = sd.hi; emit_n = 1; emit_p = reinterpret_cast<uint8_t *>(&sc->hash); break;
-        default:                // CS_RLC: only the first verifier_len + 5 coefficients are consumed (:2865-2871)
+        default:                // CS_RLC: only the first verifier_len + 4 + (num_aggregators - 1) coefficients are consumed (:2865-2871)
             usage = DST_RLC; k0 = vk0; k1 = vk1; p1 = nonce; l1 = 16;
-            emit_n = P.verifier_len + 5; emit_p = reinterpret_cast<uint8_t *>(W.rlc + (uint64_t)i * (P.verifier_len + 5));
+            emit_n = rlc_len(P); emit_p = reinterpret_cast<uint8_t *>(W.rlc + (uint64_t)i * rlc_len(P));
             break;
         }
         s.init_xof(P.alg_id, usage, k0, k1);
@@ -114,6 +115,7 @@ __device__ __forceinline__ void chain_body(const Prio3Dev &P, const Workspace &W
         s.finalize();
         if (emit_n) {
             xof_emit(s, emit_p, emit_n, P.sampler_bound);
+            if (stg == CS_RLC) fold_hash_coefficient(P, W.rlc + (uint64_t)i * rlc_len(P), d.role);
         } else {
             sd = F128{s.st[0], s.st[1]};          // Xof::into_seed
             // the locally computed parts vs the ones in the public shares (prio3.rs:2790-2805)

@@ -28,11 +28,10 @@ Vec expand(uint32_t alg, uint32_t usage, const uint8_t *seed, const uint8_t *bin
     xof_emit(s, reinterpret_cast<uint8_t *>(out.data()), n, g_sampler_bound);
     return out;
 }
-F128 derive_seed(uint32_t alg, const F128 parts[2]) {
+F128 derive_seed(uint32_t alg, const std::vector<F128> &parts) {
     Sponge s;
     s.init_xof(alg, DST_JR_SEED, 0ull, 0ull);
-    s.absorb_f(parts[0]);
-    s.absorb_f(parts[1]);
+    for (const F128 &part : parts) s.absorb_f(part);
     return s.into_seed();
 }
 void absorb_vec(Sponge &s, const Vec &v) { s.absorb(reinterpret_cast<const uint8_t *>(v.data()), (uint32_t)(16 * v.size())); }
@@ -155,67 +154,83 @@ uint8_t *put_vec(uint8_t *o, const Vec &v) { return put(o, v.data(), 16 * v.size
 using namespace wh;
 
 extern "C" int32_t wh_client_shard_batched(const wh_prio3_params *params, const uint64_t *measurement,
-                                           const uint8_t nonce[16], const uint8_t rand[144],
+                                           const uint8_t nonce[16], const uint8_t *rand,
                                            const uint8_t client_id_be[16], uint8_t *leader_report,
                                            uint8_t *helper_report) {
     Flp flp;
     flp.p = *params;
-    if (flp.p.num_aggregators != 2) return WH_ERR_PARAM;    // the batched protocol is Alice and Bob
     int32_t rc = host_sizes(flp.p, flp.z);
     if (rc) return rc;
     const HostSizes &z = flp.z;
     const uint32_t alg = z.alg_id;
-    // random_seeds order: prio3.rs:579-581, 589, 647, 705, 753, 826, 883
-    const uint8_t *h_meas_seed = rand, *h_proof_seed[2] = {rand + 16, rand + 32}, *h_jr_blind = rand + 48,
-                  *l_jr_blind = rand + 64, *prove_seed[2] = {rand + 80, rand + 96}, *h_qr_blind = rand + 112,
-                  *l_qr_blind = rand + 128;
+    // The servers are Alice and Bob; shard_batched is generic in the number of aggregators (its own test runs three,
+    // prio3.rs:3077-3085).  random_seeds order: per Helper measurement, proof 1, proof 2, joint-rand blind (prio3.rs:579-581,
+    // 589); Leader's joint-rand blind (:647); the two prove seeds (:705, :753); per Helper query-rand blind (:826); Leader's
+    // (:883): 16 (5 na - 1) bytes.
+    const uint32_t na = flp.p.num_aggregators, nh = na - 1;
+    const uint8_t *l_jr_blind = rand + 64 * (size_t)nh, *prove_seed[2] = {l_jr_blind + 16, l_jr_blind + 32},
+                  *h_qr_blinds = l_jr_blind + 48, *l_qr_blind = h_qr_blinds + 16 * (size_t)nh;
+    auto h_meas_seed = [&](uint32_t a) { return rand + 64 * (size_t)(a - 1); };
+    auto h_proof_seed = [&](uint32_t a, int t) { return rand + 64 * (size_t)(a - 1) + 16 + 16 * t; };
+    auto h_jr_blind = [&](uint32_t a) { return rand + 64 * (size_t)(a - 1) + 48; };
     Vec x;
     if ((rc = encode_measurement(flp.p, z, measurement, x))) return rc;
-    const uint8_t one = 1, zero = 0;
-    Vec h_meas = expand(alg, DST_MEAS, h_meas_seed, &one, 1, z.input_len), l_meas(z.input_len);
-    for (uint32_t i = 0; i < z.input_len; i++) l_meas[i] = f_sub(x[i], h_meas[i]);
-    F128 jr_parts[2], qr_parts[2];
+    const uint8_t zero = 0;
+    std::vector<F128> jr_parts(na), qr_parts(na);
     Sponge s;
+    Vec l_meas = x;
+    for (uint32_t a = 1; a < na; a++) {
+        const uint8_t id = (uint8_t)a;
+        Vec h_meas = expand(alg, DST_MEAS, h_meas_seed(a), &id, 1, z.input_len);
+        for (uint32_t i = 0; i < z.input_len; i++) l_meas[i] = f_sub(l_meas[i], h_meas[i]);
+        s.init_xof(alg, DST_JR_PART, h_jr_blind(a)); s.absorb(&id, 1); s.absorb(nonce, 16); absorb_vec(s, h_meas);
+        jr_parts[a] = s.into_seed();
+    }
     s.init_xof(alg, DST_JR_PART, l_jr_blind); s.absorb(&zero, 1); s.absorb(nonce, 16); absorb_vec(s, l_meas);
     jr_parts[0] = s.into_seed();
-    s.init_xof(alg, DST_JR_PART, h_jr_blind); s.absorb(&one, 1); s.absorb(nonce, 16); absorb_vec(s, h_meas);
-    jr_parts[1] = s.into_seed();
     F128 seed = derive_seed(alg, jr_parts);
     Vec jr = expand(alg, DST_JOINT_RAND, reinterpret_cast<const uint8_t *>(&seed), nullptr, 0, 2 * z.jr_len);
 
-    Vec proof[2], l_proof[2], h_proof[2], pub[2], fcoef[2], fv[2];
+    Vec proof[2], l_proof[2], pub[2], fcoef[2], fv[2];
     for (int t = 0; t < 2; t++) {                                            // prio3.rs:703-782
         Vec prove_rand = expand(alg, DST_PROVE_RAND, prove_seed[t], nullptr, 0, z.arity);
         flp.prove(x, prove_rand, jr.data() + t * z.jr_len, proof[t], fcoef[t], fv[t]);
-        h_proof[t] = expand(alg, DST_PROOF, h_proof_seed[t], &one, 1, z.proof_len);
-        l_proof[t].resize(z.proof_len);
-        for (uint32_t i = 0; i < z.proof_len; i++) l_proof[t][i] = f_sub(proof[t][i], h_proof[t][i]);
+        l_proof[t] = proof[t];
+        for (uint32_t a = 1; a < na; a++) {
+            const uint8_t id = (uint8_t)a;
+            const Vec h = expand(alg, DST_PROOF, h_proof_seed(a, t), &id, 1, z.proof_len);
+            for (uint32_t i = 0; i < z.proof_len; i++) l_proof[t][i] = f_sub(l_proof[t][i], h[i]);
+        }
+    }
+    for (uint32_t a = 1; a < na; a++) {                                      // prio3.rs:806-874
+        const uint8_t id = (uint8_t)a;
+        s.init_xof(alg, DST_QR_PART, h_qr_blinds + 16 * (size_t)(a - 1)); absorb_vec(s, jr);
+        for (int t = 0; t < 2; t++) absorb_vec(s, expand(alg, DST_PROOF, h_proof_seed(a, t), &id, 1, z.proof_len));
+        qr_parts[a] = s.into_seed();
     }
     s.init_xof(alg, DST_QR_PART, l_qr_blind); absorb_vec(s, jr); absorb_vec(s, l_proof[0]); absorb_vec(s, l_proof[1]);
     qr_parts[0] = s.into_seed();
-    s.init_xof(alg, DST_QR_PART, h_qr_blind); absorb_vec(s, jr); absorb_vec(s, h_proof[0]); absorb_vec(s, h_proof[1]);
-    qr_parts[1] = s.into_seed();
     seed = derive_seed(alg, qr_parts);  // DST_JR_SEED again, prio3.rs:933
     Vec qr = expand(alg, DST_QUERY_RAND, reinterpret_cast<const uint8_t *>(&seed), nullptr, 0, 2);
     for (int t = 0; t < 2; t++)
         if ((rc = flp.public_proof(x, proof[t], fcoef[t], fv[t], jr.data() + t * z.jr_len, qr[t], pub[t]))) return rc;
 
-    for (int a = 0; a < 2; a++) {
-        uint8_t *o = a ? helper_report : leader_report;
+    for (uint32_t a = 0; a < na; a++) {
+        uint8_t *o = a ? helper_report + (size_t)(a - 1) * z.helper_len : leader_report;
         o = put(o, client_id_be, 16);
-        o = put(o, jr_parts, 32);
+        o = put(o, jr_parts.data(), 16 * (size_t)na);
         *o++ = (uint8_t)a;
         if (a == 0) {
             o = put_vec(o, l_meas); o = put_vec(o, l_proof[0]); o = put(o, l_jr_blind, 16); o = put_vec(o, l_proof[1]);
         } else {
-            o = put(o, h_meas_seed, 16); o = put(o, h_proof_seed[0], 16); o = put(o, h_jr_blind, 16); o = put(o, h_proof_seed[1], 16);
+            o = put(o, h_meas_seed(a), 16); o = put(o, h_proof_seed(a, 0), 16); o = put(o, h_jr_blind(a), 16); o = put(o, h_proof_seed(a, 1), 16);
         }
-        o = put(o, qr_parts, 32);
+        o = put(o, qr_parts.data(), 16 * (size_t)na);
         uint8_t nq[8];
         for (int i = 0; i < 8; i++) nq[i] = (uint8_t)((uint64_t)z.verifier_len >> (56 - 8 * i));
         o = put(o, nq, 8);
         o = put_vec(o, pub[0]); o = put_vec(o, pub[1]);
-        o = put(o, a ? h_qr_blind : l_qr_blind, 16);
+        o = put(o, a ? h_qr_blinds + 16 * (size_t)(a - 1) : l_qr_blind, 16);
         o = put(o, nonce, 16);
     }
     return WH_OK;
@@ -225,9 +240,9 @@ extern "C" int32_t wh_client_shard_many(const wh_prio3_params *params, const uin
                                         const uint8_t *nonces, const uint8_t *rands, uint64_t first_client_id, uint64_t n,
                                         uint32_t nthreads, uint8_t *leader_reports, uint8_t *helper_reports) {
     HostSizes z;
-    if (params->num_aggregators != 2) return WH_ERR_PARAM;
     int32_t rc = host_sizes(*params, z);
     if (rc) return rc;
+    const uint64_t nh = params->num_aggregators - 1, rand_len = 16 * (5ull * params->num_aggregators - 1);
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 64) nthreads = 64;
     std::vector<int32_t> rcs(nthreads, 0);
@@ -236,9 +251,9 @@ extern "C" int32_t wh_client_shard_many(const wh_prio3_params *params, const uin
             uint8_t id[16] = {0};
             uint64_t cid = first_client_id + i;
             for (int b = 0; b < 8; b++) id[15 - b] = (uint8_t)(cid >> (8 * b));
-            int32_t r = wh_client_shard_batched(params, measurements + i * meas_words, nonces + 16 * i, rands + 144 * i, id,
+            int32_t r = wh_client_shard_batched(params, measurements + i * meas_words, nonces + 16 * i, rands + rand_len * i, id,
                                                 leader_reports + i * (uint64_t)z.leader_len,
-                                                helper_reports + i * (uint64_t)z.helper_len);
+                                                helper_reports + i * nh * (uint64_t)z.helper_len);
             if (r) rcs[t] = r;
         }
     };

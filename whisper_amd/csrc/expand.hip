@@ -29,7 +29,7 @@ __device__ __forceinline__ void expand_body(const Prio3Dev &P, const Workspace &
         const uint8_t *seed = which ? seeds + (t ? 48 : 16) : seeds;
         uint8_t *out = const_cast<uint8_t *>(which ? ((t || P.mode) ? d.proof2 : d.proof1) : d.meas);
         s.init_xof(P.alg_id, which ? DST_PROOF : DST_MEAS, seed);
-        s.absorb3(P.mode ? d.base : d.base + 48, 1, nullptr, 0, nullptr, 0);   // binder = [agg_id]
+        s.absorb3(P.mode ? d.base : d.base + 16 + 16 * P.num_aggregators, 1, nullptr, 0, nullptr, 0);   // binder = [agg_id]
         s.finalize();
         xof_emit(s, out, which ? P.proof_len : P.input_len, P.sampler_bound);
     }

@@ -44,7 +44,8 @@ inline int32_t host_sizes(const wh_prio3_params &p, HostSizes &s) {
     s.gpoly_len = 2 * (s.m - 1) + 1;
     s.proof_len = s.arity + s.gpoly_len;
     s.verifier_len = 2 + s.arity;
-    uint32_t common = 16 + 32 + 1 + 32 + 8 + 2 * 16 * s.verifier_len + 16 + 16;
+    // VdafBatchedKey (vdaf.rs:148-162): client id | parts | agg id | share | parts | num_queries | 2 public proofs | blind | nonce
+    uint32_t common = 16 + 16 * p.num_aggregators + 1 + 16 * p.num_aggregators + 8 + 2 * 16 * s.verifier_len + 16 + 16;
     s.leader_len = common + 16 * (s.input_len + 2 * s.proof_len) + 16;
     s.helper_len = common + 64;
     return WH_OK;

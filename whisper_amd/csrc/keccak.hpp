@@ -268,11 +268,19 @@ struct SpongeT {
         pos = 0;
     }
 
-    // st[idx] ^= w with idx only known at run time.  On the device idx is wave-uniform; the
-    // readfirstlane makes the switch a scalar branch tree instead of 21 exec-masked bodies.
+    // st[idx] ^= w with idx only known at run time.  On the device idx is wave-uniform almost always; the
+    // readfirstlane makes the switch a scalar branch tree instead of 21 exec-masked bodies.  Lanes CAN be out of phase: a
+    // wavefront that holds reports of different roles absorbs segments of different lengths (the joint-rand seed's parts
+    // before and after the own one), so the uniform path is taken only when the active lanes agree.
     WH_HD void xor_word(uint32_t idx, uint64_t w) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        idx = __builtin_amdgcn_readfirstlane(idx);
+        const uint32_t first = __builtin_amdgcn_readfirstlane(idx);
+        if (__builtin_expect(!__all(idx == first), 0)) {
+#pragma unroll
+            for (uint32_t i = 0; i < RATE_WORDS; i++) st[i] ^= idx == i ? w : 0;
+            return;
+        }
+        idx = first;
 #endif
         switch (idx) {
 #define C_(i) case i: st[i] ^= w; break;

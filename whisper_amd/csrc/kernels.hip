@@ -62,19 +62,21 @@ __global__ void k_parse(Prio3Dev P, Workspace W, const uint8_t *blob, const uint
     RepDesc d;
     d.base = rep; d.meas = d.proof1 = d.proof2 = d.tail = d.jr_blind = d.seeds = nullptr; d.role = 0; d.hslot = 0;
     int32_t st = ST_OK;
-    if (rep_len < 49) st = ST_ERR_SHORT;
+    // client id | num_aggregators joint-rand parts | agg id | share | ... (vdaf.rs:148-162); psb = bytes of a public share
+    const uint64_t psb = 16ull * P.num_aggregators, head = 17 + psb;
+    if (rep_len < head) st = ST_ERR_SHORT;
     if (!st) {
-        d.role = rep[48];
-        if (d.role >= 2) st = ST_ERR_AGG_ID;
+        d.role = rep[16 + psb];
+        if (d.role >= P.num_aggregators) st = ST_ERR_AGG_ID;
     }
     if (!st) {
         uint64_t share_len = d.role == 0 ? 16ull * (P.input_len + 2ull * P.proof_len) + 16 : 64;
-        uint64_t off = 49 + share_len;
-        if (rep_len < off + 40) st = ST_ERR_SHORT;
+        uint64_t off = head + share_len;
+        if (rep_len < off + psb + 8) st = ST_ERR_SHORT;
         if (!st) {
             d.tail = rep + off;
-            uint64_t nq = be64(rep + off + 32);
-            uint64_t rest = rep_len - (off + 40);
+            uint64_t nq = be64(rep + off + psb);
+            uint64_t rest = rep_len - (off + psb + 8);
             if (nq != P.verifier_len) {
                 st = (nq > rest / 32 || rest - 32 * nq < 32) ? ST_ERR_SHORT : ST_ERR_NUM_QUERIES;
             } else if (rest < 32ull * P.verifier_len + 32) {
@@ -84,7 +86,7 @@ __global__ void k_parse(Prio3Dev P, Workspace W, const uint8_t *blob, const uint
     }
     if (!st) {
         if (d.role == 0) {
-            d.meas = rep + 49;
+            d.meas = rep + head;
             d.proof1 = d.meas + 16ull * P.input_len;
             d.jr_blind = d.proof1 + 16ull * P.proof_len;
             d.proof2 = d.jr_blind + 16;
@@ -95,8 +97,8 @@ __global__ void k_parse(Prio3Dev P, Workspace W, const uint8_t *blob, const uint
             d.meas = row;
             d.proof1 = row + 16ull * P.input_len;
             d.proof2 = d.proof1 + 16ull * P.proof_len;
-            d.jr_blind = rep + 49 + 32;
-            d.seeds = rep + 49;
+            d.jr_blind = rep + head + 32;
+            d.seeds = rep + head;
         }
     }
     // the later kernels run per role over the two lists; a malformed report is in neither and
@@ -149,9 +151,10 @@ __global__ void __launch_bounds__(256) WH_HASH_ATTR k_hash(Prio3Dev P, Workspace
     if (!report_of_slot(W, slot, i) || status[i] != ST_OK) return;
     const RepDesc d = W.desc[i];
     RepScal *sc = &W.scal[i];
+    const uint32_t psb = 16 * P.num_aggregators;    // bytes of a public share: one part per aggregator
     const uint8_t *ps_parts = d.base + 16;
     const uint8_t *ps2_parts = d.tail;
-    const uint8_t *pp = d.tail + 40;
+    const uint8_t *pp = d.tail + psb + 8;
     const uint8_t *qr_blind = pp + 32ull * P.verifier_len;
     const uint8_t *nonce = qr_blind + 16;
     const uint32_t njr = 2 * P.jr_len;
@@ -169,8 +172,9 @@ __global__ void __launch_bounds__(256) WH_HASH_ATTR k_hash(Prio3Dev P, Workspace
         case 1:  // joint-rand seed over the parts, own part at index role
         case 4: {
             const uint8_t *parts = stg == 1 ? ps_parts : ps2_parts;
-            usage = DST_JR_SEED; l1 = 16; l2 = 16;
-            if (d.role == 0) { p1 = own; p2 = parts + 16; } else { p1 = parts; p2 = own; }
+            usage = DST_JR_SEED;
+            // (segment lengths depend on the role: lanes of a wavefront that mixes roles go out of phase, keccak.hpp xor_word)
+            p1 = parts; l1 = 16 * d.role; p2 = own; l2 = 16; p3 = parts + 16 * (d.role + 1); l3 = psb - 16 * (d.role + 1);
             break;
         }
         case 2: usage = DST_JOINT_RAND; k0 = sd.lo; k1 = sd.hi; emit_n = njr; emit_p = reinterpret_cast<uint8_t *>(sc->jr); break;
@@ -181,12 +185,12 @@ __global__ void __launch_bounds__(256) WH_HASH_ATTR k_hash(Prio3Dev P, Workspace
             break;
         case 5: usage = DST_QUERY_RAND; k0 = sd.lo; k1 = sd.hi; emit_n = 2; emit_p = reinterpret_cast<uint8_t *>(sc->qr); break;
         case 8:  // hash of the public parts: XOF(0, 10) . parts . parts2 . enc(pp0) . enc(pp1)
-            usage = DST_HASH; p1 = ps_parts; l1 = 32; p2 = ps2_parts; l2 = 32; p3 = pp; l3 = 32u * P.verifier_len;
+            usage = DST_HASH; p1 = ps_parts; l1 = psb; p2 = ps2_parts; l2 = psb; p3 = pp; l3 = 32u * P.verifier_len;
             break;
         case 9: usage = DST_HASH; k0 = sd.lo; k1 = sd.hi; emit_n = 1; emit_p = reinterpret_cast<uint8_t *>(&sc->hash); break;
-        default:  // 10: RLC coefficients; only the first verifier_len + 5 are consumed (:2865-2871)
+        default:  // 10: RLC coefficients; only the first verifier_len + 4 + (num_aggregators - 1) are consumed (:2865-2871)
             usage = DST_RLC; k0 = vk0; k1 = vk1; p1 = nonce; l1 = 16;
-            emit_n = P.verifier_len + 5; emit_p = reinterpret_cast<uint8_t *>(W.rlc + (uint64_t)i * (P.verifier_len + 5));
+            emit_n = rlc_len(P); emit_p = reinterpret_cast<uint8_t *>(W.rlc + (uint64_t)i * rlc_len(P));
             break;
         }
         s.init_xof(P.alg_id, usage, k0, k1);
@@ -194,6 +198,7 @@ __global__ void __launch_bounds__(256) WH_HASH_ATTR k_hash(Prio3Dev P, Workspace
         s.finalize();
         if (emit_n) {
             xof_emit(s, emit_p, emit_n, P.sampler_bound);
+            if (which && stg == 2) fold_hash_coefficient(P, W.rlc + (uint64_t)i * rlc_len(P), d.role);
         } else {
             sd = F128{s.st[0], s.st[1]};          // Xof::into_seed
             if (!which && stg == 3) {
@@ -513,8 +518,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WH_Q_W
     uint4 *stage = reinterpret_cast<uint4 *>(sh + 1) + (uint64_t)wave * QT_STAGE_U4;
     const RepDesc d = W.desc[i];
     const RepScal *sc = &W.scal[i];
-    const uint8_t *pp0 = d.tail + 40, *pp1 = pp0 + 16ull * P.verifier_len;
-    const F128 *rlc = W.rlc + (uint64_t)i * (P.verifier_len + 5);
+    const uint8_t *pp0 = d.tail + 16 * P.num_aggregators + 8, *pp1 = pp0 + 16ull * P.verifier_len;
+    const F128 *rlc = W.rlc + (uint64_t)i * rlc_len(P);
     const bool leader = d.role == 0;
     uint32_t bad = 0;                           // any element >= p (FieldError::ModulusOverflow)
 
@@ -892,8 +897,8 @@ __global__ void __launch_bounds__(256) k_query_polyeval(Prio3Dev P, Workspace W,
     const RepDesc d = W.desc[i];
     const RepScal *sc = &W.scal[i];
     const RepPow *pw = &W.pows[i];
-    const uint8_t *pp0 = d.tail + 40, *pp1 = pp0 + 16ull * P.verifier_len;
-    const uint8_t *rlc = reinterpret_cast<const uint8_t *>(W.rlc + (uint64_t)i * (P.verifier_len + 5));
+    const uint8_t *pp0 = d.tail + 16 * P.num_aggregators + 8, *pp1 = pp0 + 16ull * P.verifier_len;
+    const uint8_t *rlc = reinterpret_cast<const uint8_t *>(W.rlc + (uint64_t)i * rlc_len(P));
     const uint8_t *Lg = reinterpret_cast<const uint8_t *>(W.weights + (uint64_t)i * P.n_weights);
     const bool leader = d.role == 0;
     uint32_t bad = 0;
@@ -1082,8 +1087,8 @@ __global__ void __launch_bounds__(256) WH_QTINY_ATTR k_query_psum_tiny(Prio3Dev 
     const RepDesc d = W.desc[i];
     const RepScal *sc = &W.scal[i];
     const RepPow *pw = &W.pows[i];
-    const uint8_t *pp0 = d.tail + 40, *pp1 = pp0 + 16ull * vl;
-    const uint8_t *rlc = reinterpret_cast<const uint8_t *>(W.rlc + (uint64_t)i * (vl + 5));
+    const uint8_t *pp0 = d.tail + 16 * P.num_aggregators + 8, *pp1 = pp0 + 16ull * vl;
+    const uint8_t *rlc = reinterpret_cast<const uint8_t *>(W.rlc + (uint64_t)i * rlc_len(P));
     const bool leader = d.role == 0;
     const bool act = lane < chunk;
     const uint32_t k = act ? lane : 0;

@@ -120,8 +120,8 @@ __device__ __forceinline__ void meas_body(const Prio3Dev &P, const Workspace &W,
     }
     if (status[i] != ST_OK) return;
     const RepDesc d = W.desc[i];
-    const uint8_t *agg_id = P.mode ? d.base : d.base + 48;
-    const uint8_t *nonce = P.mode ? d.tail : d.tail + 40 + 32ull * P.verifier_len + 16;
+    const uint8_t *agg_id = P.mode ? d.base : d.base + 16 + 16 * P.num_aggregators;
+    const uint8_t *nonce = P.mode ? d.tail : d.tail + 16 * P.num_aggregators + 8 + 32ull * P.verifier_len + 16;
     const F128 bound = P.sampler_bound;
 
     SpongeG s;

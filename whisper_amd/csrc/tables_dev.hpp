@@ -17,6 +17,21 @@ __device__ __forceinline__ F128 f_pow_u32(F128 x, uint32_t e) {
     return r;
 }
 
+// RLC coefficients of a batched report (prio3.rs:2859-2871): verifier_len differences, 2 decide flags, 2 part checks and
+// num_aggregators - 1 shares of zero made from the hash of the public parts
+__host__ __device__ __forceinline__ uint32_t rlc_len(const Prio3Dev &P) { return P.verifier_len + 4 + (P.num_aggregators - 1); }
+// The query kernels multiply ONE coefficient, rlc[verifier_len + 4], by -H (Leader) or +H (Helper).  With more than two
+// aggregators the Leader's share of zero is -H at every one of the num_aggregators - 1 positions and Helper a's is +H at
+// position a - 1 (prio3.rs:2844-2855): the lane that emits the coefficients folds that into the one slot.
+__device__ __forceinline__ void fold_hash_coefficient(const Prio3Dev &P, F128 *rlc, uint32_t role) {
+    if (P.num_aggregators == 2) return;
+    F128 *c = rlc + P.verifier_len + 4;
+    if (role) { c[0] = c[role - 1]; return; }
+    F128 acc = c[0];
+    for (uint32_t j = 1; j + 1 < P.num_aggregators; j++) acc = f_add(acc, c[j]);
+    c[0] = acc;
+}
+
 // Report handled by slot `slot` of a per-report kernel: the well-formed Leader-role reports
 // first, then the Helper-role ones, so that a wavefront (almost always) holds one role only.
 __device__ __forceinline__ bool report_of_slot(const Workspace &W, uint32_t slot, uint32_t &i) {

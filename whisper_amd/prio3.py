@@ -63,17 +63,19 @@ def flp_prove(params, inp, prove_rand, joint_rand):
 def shard_batched_many(params, measurements, nonces, rands, first_client_id=0, nthreads=8):
     """CPU client: client-batch-prio3/src/main.rs:67-153 for n clients.
 
-    measurements: uint64 [n, words]; nonces: uint8 [n,16]; rands: uint8 [n,144].
-    Returns (leader_reports uint8 [n, leader_len], helper_reports uint8 [n, helper_len])."""
+    measurements: uint64 [n, words]; nonces: uint8 [n,16]; rands: uint8 [n, 16 (5 num_aggregators - 1)] (144 for two).
+    Returns (leader_reports uint8 [n, leader_len], helper_reports uint8 [n, helper_len]); with more than two aggregators
+    helper_reports is [n, num_aggregators - 1, helper_len], aggregator 1 first."""
     meas = np.ascontiguousarray(measurements, dtype=np.uint64)
     if meas.ndim == 1:
         meas = meas.reshape(-1, 1)
     n = meas.shape[0]
+    na = params.c.num_aggregators
     nonces = np.ascontiguousarray(nonces, dtype=np.uint8).reshape(n, 16)
-    rands = np.ascontiguousarray(rands, dtype=np.uint8).reshape(n, 144)
+    rands = np.ascontiguousarray(rands, dtype=np.uint8).reshape(n, 16 * (5 * na - 1))
     s = params.sizes
     lr = np.zeros((n, s.leader_report_len), np.uint8)
-    hr = np.zeros((n, s.helper_report_len), np.uint8)
+    hr = np.zeros((n, s.helper_report_len) if na == 2 else (n, na - 1, s.helper_report_len), np.uint8)
     rc = lib.wh_client_shard_many(C.byref(params.c), meas.ctypes.data, meas.shape[1], nonces.ctypes.data,
                                   rands.ctypes.data, first_client_id, n, nthreads, lr.ctypes.data, hr.ctypes.data)
     if rc:
