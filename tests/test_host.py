@@ -42,10 +42,39 @@ def test_sizes_match_oracle():
         W.Prio3Params(0, 16, 0, 4)
     with pytest.raises(W.WhError):
         W.Prio3Params(0, 16, 4, 4, num_aggregators=1)
-    # three aggregators exist for the draft-07 prepare_init path only; the batched client refuses them
-    p3 = W.Prio3Params(0, 16, 4, 4, num_aggregators=3)
-    with pytest.raises(W.WhError):
-        make_reports(p3, 1, seed=1)
+    # a public share carries one 16-byte part per aggregator, twice per report (vdaf.rs:148-162)
+    for na in (3, 5):
+        p3, s3 = W.Prio3Params(0, 16, 4, 4, num_aggregators=na), O.sizes(O.params(0, 16, 4, 4, num_aggregators=na))
+        p2 = W.Prio3Params(0, 16, 4, 4)
+        assert p3.sizes.leader_report_len == s3.leader_report_len == p2.sizes.leader_report_len + 32 * (na - 2)
+        assert p3.sizes.helper_report_len == s3.helper_report_len == p2.sizes.helper_report_len + 32 * (na - 2)
+
+
+@pytest.mark.parametrize("na", (3, 4))
+@pytest.mark.parametrize("circ,bits,ln,ch", [(0, 16, 3, 7), (1, 0, 11, 3), (2, 8, 0, 0)])
+def test_client_matches_oracle_sharder_many_aggregators(circ, bits, ln, ch, na):
+    """shard_batched is generic in the number of aggregators (prio3.rs:537-991; its own test runs three, :3077-3085): the CPU
+    client and the oracle's sharder agree byte for byte, and the oracle's prepare_batched on every aggregator's report gives
+    proof tags that cancel (vdaf.rs:889-897; prepare_encoded_key negates a Helper's, main.rs:53-59)."""
+    from common import measurements
+    p = W.Prio3Params(circ, bits, ln, ch, num_aggregators=na)
+    op = O.params(circ, bits, ln, ch, num_aggregators=na)
+    n = 3
+    meas = measurements(p, n, 9)
+    nonces = det(b"nonce9", 16 * n).reshape(n, 16)
+    rands = det(b"rand9", 16 * (5 * na - 1) * n).reshape(n, -1)
+    lr, hr = W.shard_batched_many(p, meas, nonces, rands, 11, 2)
+    assert hr.shape == (n, na - 1, p.sizes.helper_report_len)
+    vk = bytes(range(16))
+    for i in range(n):
+        l2, h2 = O.prio3_shard_batched(op, [int(x) for x in meas[i]], nonces[i].tobytes(), rands[i].tobytes(), 11 + i)
+        assert lr[i].tobytes() == l2 and hr[i].tobytes() == h2
+        tags = []
+        for a in range(na):
+            rc, tag, tid, out = O.prio3_prepare_encoded_key(op, vk, l2 if a == 0 else hr[i, a - 1].tobytes())
+            assert rc == 0
+            tags.append(int.from_bytes(tag, "little"))
+        assert tags[0] == sum(tags[1:]) % O.P128
 
 
 @pytest.mark.parametrize("circ,bits,ln,ch", [(0, 2, 5, 3), (0, 16, 3, 7), (0, 16, 16, 8), (1, 0, 4, 2), (1, 0, 11, 3), (2, 64, 0, 0), (2, 8, 0, 0)])
