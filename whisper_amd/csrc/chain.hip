@@ -64,8 +64,10 @@ __device__ __forceinline__ void chain_body(const Prio3Dev &P, const Workspace &W
     SpongeT<true, PRIO> s;
     s.slot = PRIO < 0 ? wave_slot() : 0;
     F128 sd = f_zero();
+    uint32_t sub = 0;                   // seed stages: first part of this pass (three parts a pass, wave-uniform)
 #pragma unroll 1
     for (uint32_t stg = first; stg <= last; stg++) {
+        bool last_sub = true;
         uint32_t usage = 0, l1 = 0, l2 = 0, l3 = 0, emit_n = 0;
         uint64_t k0 = 0, k1 = 0;
         const uint8_t *p1 = nullptr, *p2 = nullptr, *p3 = nullptr;
@@ -91,7 +93,7 @@ __device__ __forceinline__ void chain_body(const Prio3Dev &P, const Workspace &W
         case CS_QR_SEED: {      // the same function, DST_JR_SEED included, for the query randomness (:2651-2665)
             const uint8_t *parts = stg == CS_JR_SEED ? ps_parts : ps2_parts;
             usage = DST_JR_SEED;
-            p1 = parts; l1 = 16 * d.role; p2 = own; l2 = 16; p3 = parts + 16 * (d.role + 1); l3 = psb - 16 * (d.role + 1);
+            last_sub = seed_parts(parts, own, d.role, P.num_aggregators, sub, p1, l1, p2, l2, p3, l3);
             break;
         }
         case CS_JR: usage = DST_JOINT_RAND; k0 = sd.lo; k1 = sd.hi; emit_n = njr; emit_p = reinterpret_cast<uint8_t *>(sc->jr); break;
@@ -110,8 +112,10 @@ __device__ __forceinline__ void chain_body(const Prio3Dev &P, const Workspace &W
             emit_n = rlc_len(P); emit_p = reinterpret_cast<uint8_t *>(W.rlc + (uint64_t)i * rlc_len(P));
             break;
         }
-        s.init_xof(P.alg_id, usage, k0, k1);
+        if (!sub) s.init_xof(P.alg_id, usage, k0, k1);
         s.template absorb3<PREFETCH>(p1, l1, p2, l2, p3, l3);
+        if (!last_sub) { sub += 3; stg--; continue; }       // more than three aggregators: the same sponge, the next parts
+        sub = 0;
         s.finalize();
         if (emit_n) {
             xof_emit(s, emit_p, emit_n, P.sampler_bound);

@@ -268,19 +268,16 @@ struct SpongeT {
         pos = 0;
     }
 
-    // st[idx] ^= w with idx only known at run time.  On the device idx is wave-uniform almost always; the
-    // readfirstlane makes the switch a scalar branch tree instead of 21 exec-masked bodies.  Lanes CAN be out of phase: a
-    // wavefront that holds reports of different roles absorbs segments of different lengths (the joint-rand seed's parts
-    // before and after the own one), so the uniform path is taken only when the active lanes agree.
+    // st[idx] ^= w with idx only known at run time.  On the device idx MUST be wave-uniform: the readfirstlane makes the
+    // switch a scalar branch tree instead of 21 exec-masked bodies (which cost the chain kernel 70 spilled registers).
+    // So every active lane of a wavefront has to absorb segments of the same LENGTHS (the pointers may differ): a sponge
+    // whose segment lengths depend on the report -- the joint-rand seed over "the parts before the own one, the own part,
+    // the parts after it" -- puts lanes of different aggregator ids out of phase, and this function then XORs one lane's
+    // word index for all (round 2's un-batched path did, in batches that mixed ids).  The seed sponges therefore absorb
+    // part by part, 16 bytes from a per-lane pointer (kernels.hip / chain.hip: seed_parts).
     WH_HD void xor_word(uint32_t idx, uint64_t w) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        const uint32_t first = __builtin_amdgcn_readfirstlane(idx);
-        if (__builtin_expect(!__all(idx == first), 0)) {
-#pragma unroll
-            for (uint32_t i = 0; i < RATE_WORDS; i++) st[i] ^= idx == i ? w : 0;
-            return;
-        }
-        idx = first;
+        idx = __builtin_amdgcn_readfirstlane(idx);
 #endif
         switch (idx) {
 #define C_(i) case i: st[i] ^= w; break;

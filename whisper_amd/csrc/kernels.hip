@@ -162,8 +162,10 @@ __global__ void __launch_bounds__(256) WH_HASH_ATTR k_hash(Prio3Dev P, Workspace
     SpongeG s;
     F128 sd = f_zero();
     const uint32_t nst = which ? 3 : 6;
+    uint32_t sub = 0;                   // seed stages: first part of this pass (three parts a pass, wave-uniform)
 #pragma unroll 1
     for (uint32_t stg = which ? 0 : 1; stg < nst; stg++) {     // job A's stage 0 (the own joint-rand part) is k_meas
+        bool last_sub = true;
         uint32_t usage = 0, l1 = 0, l2 = 0, l3 = 0, emit_n = 0;
         uint64_t k0 = 0, k1 = 0;
         const uint8_t *p1 = nullptr, *p2 = nullptr, *p3 = nullptr;
@@ -173,8 +175,7 @@ __global__ void __launch_bounds__(256) WH_HASH_ATTR k_hash(Prio3Dev P, Workspace
         case 4: {
             const uint8_t *parts = stg == 1 ? ps_parts : ps2_parts;
             usage = DST_JR_SEED;
-            // (segment lengths depend on the role: lanes of a wavefront that mixes roles go out of phase, keccak.hpp xor_word)
-            p1 = parts; l1 = 16 * d.role; p2 = own; l2 = 16; p3 = parts + 16 * (d.role + 1); l3 = psb - 16 * (d.role + 1);
+            last_sub = seed_parts(parts, own, d.role, P.num_aggregators, sub, p1, l1, p2, l2, p3, l3);
             break;
         }
         case 2: usage = DST_JOINT_RAND; k0 = sd.lo; k1 = sd.hi; emit_n = njr; emit_p = reinterpret_cast<uint8_t *>(sc->jr); break;
@@ -193,8 +194,10 @@ __global__ void __launch_bounds__(256) WH_HASH_ATTR k_hash(Prio3Dev P, Workspace
             emit_n = rlc_len(P); emit_p = reinterpret_cast<uint8_t *>(W.rlc + (uint64_t)i * rlc_len(P));
             break;
         }
-        s.init_xof(P.alg_id, usage, k0, k1);
+        if (!sub) s.init_xof(P.alg_id, usage, k0, k1);
         s.absorb3<WH_HASH_PREFETCH>(p1, l1, p2, l2, p3, l3);
+        if (!last_sub) { sub += 3; stg--; continue; }       // more than three aggregators: the same sponge, the next parts
+        sub = 0;
         s.finalize();
         if (emit_n) {
             xof_emit(s, emit_p, emit_n, P.sampler_bound);
@@ -285,8 +288,10 @@ __global__ void __launch_bounds__(256) k_hash_base(Prio3Dev P, Workspace W, uint
     uint8_t *own = reinterpret_cast<uint8_t *>(&sc->own);
     SpongeG s;
     F128 sd = f_zero();
+    uint32_t sub = 0;                   // seed stage: first part of this pass (three parts a pass, wave-uniform)
 #pragma unroll 1
     for (uint32_t stg = first_stage; stg < 4; stg++) {
+        bool last_sub = true;
         uint32_t usage = 0, l1 = 0, l2 = 0, l3 = 0, emit_n = 0;
         uint64_t k0 = 0, k1 = 0;
         const uint8_t *p1 = nullptr, *p2 = nullptr, *p3 = nullptr;
@@ -298,8 +303,7 @@ __global__ void __launch_bounds__(256) k_hash_base(Prio3Dev P, Workspace W, uint
             break;
         case 1:
             usage = DST_JR_SEED;
-            p1 = parts; l1 = 16 * d.role; p2 = own; l2 = 16;
-            p3 = parts + 16 * (d.role + 1); l3 = 16 * (P.num_aggregators - 1 - d.role);
+            last_sub = seed_parts(parts, own, d.role, P.num_aggregators, sub, p1, l1, p2, l2, p3, l3);
             break;
         case 2:
             usage = DST_JOINT_RAND; k0 = sd.lo; k1 = sd.hi; emit_n = P.jr_len;
@@ -310,8 +314,10 @@ __global__ void __launch_bounds__(256) k_hash_base(Prio3Dev P, Workspace W, uint
             emit_p = reinterpret_cast<uint8_t *>(sc->qr + 1);
             break;
         }
-        s.init_xof(P.alg_id, usage, k0, k1);
+        if (!sub) s.init_xof(P.alg_id, usage, k0, k1);
         s.absorb3(p1, l1, p2, l2, p3, l3);
+        if (!last_sub) { sub += 3; stg--; continue; }
+        sub = 0;
         s.finalize();
         if (emit_n) {
             xof_emit(s, emit_p, emit_n, P.sampler_bound);

@@ -32,6 +32,18 @@ __device__ __forceinline__ void fold_hash_coefficient(const Prio3Dev &P, F128 *r
     c[0] = acc;
 }
 
+// derive_joint_rand_seed over the parts with the own one substituted (prio3.rs:482-493, 2564-2578), three parts per pass
+// through the caller's sponge loop: parts a0, a0 + 1, a0 + 2 as 16-byte segments from per-lane pointers, so that lanes of
+// different aggregator ids stay in phase (keccak.hpp: xor_word).  Returns true when these were the last parts.
+__device__ __forceinline__ bool seed_parts(const uint8_t *parts, const uint8_t *own, uint32_t role, uint32_t na, uint32_t a0,
+                                           const uint8_t *&p1, uint32_t &l1, const uint8_t *&p2, uint32_t &l2,
+                                           const uint8_t *&p3, uint32_t &l3) {
+    p1 = a0 == role ? own : parts + 16 * a0; l1 = 16;
+    if (a0 + 1 < na) { p2 = a0 + 1 == role ? own : parts + 16 * (a0 + 1); l2 = 16; }
+    if (a0 + 2 < na) { p3 = a0 + 2 == role ? own : parts + 16 * (a0 + 2); l3 = 16; }
+    return a0 + 3 >= na;
+}
+
 // Report handled by slot `slot` of a per-report kernel: the well-formed Leader-role reports
 // first, then the Helper-role ones, so that a wavefront (almost always) holds one role only.
 __device__ __forceinline__ bool report_of_slot(const Workspace &W, uint32_t slot, uint32_t &i) {
