@@ -154,7 +154,10 @@ k_chain(Prio3Dev P, Workspace W, uint32_t npad, uint64_t vk0, uint64_t vk1, int3
 #endif
 }
 // the same with the next rate block's loads in flight under the permutation (42 more VGPRs: three wavefronts a SIMD)
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+#ifndef WH_CHAIN_PF_WAVES
+#define WH_CHAIN_PF_WAVES 3
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WH_CHAIN_PF_WAVES, WH_CHAIN_PF_WAVES)))
 k_chain_prefetch(Prio3Dev P, Workspace W, uint32_t npad, uint64_t vk0, uint64_t vk1, int32_t *status) {
     chain_body<true, WH_CHAIN_PRIO_MODE == 1 ? -1 : 0>(P, W, npad, vk0, vk1, status);
 }
