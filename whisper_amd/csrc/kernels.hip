@@ -183,6 +183,9 @@ __global__ void __launch_bounds__(256) WH_HASH_ATTR k_hash(Prio3Dev P, Workspace
             usage = DST_QR_PART; k0 = ld64(qr_blind); k1 = ld64(qr_blind + 8);
             p1 = reinterpret_cast<const uint8_t *>(sc->jr); l1 = 16 * njr;
             p2 = d.proof1; l2 = 16u * P.proof_len; p3 = d.proof2; l3 = 16u * P.proof_len;
+#if defined(WH_HASH_EXP) && WH_HASH_EXP == 2        // timing experiment (results invalid): the proof shares are not absorbed
+            l2 = l3 = 0;
+#endif
             break;
         case 5: usage = DST_QUERY_RAND; k0 = sd.lo; k1 = sd.hi; emit_n = 2; emit_p = reinterpret_cast<uint8_t *>(sc->qr); break;
         case 8:  // hash of the public parts: XOF(0, 10) . parts . parts2 . enc(pp0) . enc(pp1)
@@ -216,7 +219,9 @@ __global__ void __launch_bounds__(256) WH_HASH_ATTR k_hash(Prio3Dev P, Workspace
         F128 r1 = sc->qr[0], r = sc->qr[1];
         F128 r1m = f_sqr_n(r1, P.log2m), rm = f_sqr_n(r, P.log2m);
         if (f_eq(r1m, f_one()) || f_eq(rm, f_one())) { status[i] = ST_ERR_QUERY_RAND; return; }
+#if !(defined(WH_HASH_EXP) && WH_HASH_EXP == 1)     // timing experiment (results invalid): no weights and tables
         weights_and_tables(P, W, i, r, rm, sc->jr[P.jr_len]);
+#endif
     }
 }
 
