@@ -101,7 +101,7 @@ def main():
                          "(the step is then prepare + masked aggregate with a ready-made mask)")
     ap.add_argument("--with-sort", dest="with_sort", action="store_true", help="(default) the whole GPU side of the server step")
     ap.add_argument("--no-extra", action="store_true",
-                    help="default run only: skip the short lines for the other Prio3 configurations (config 1, Histogram, Average) under `extra`")
+                    help="default run only: skip the short lines for the other configurations (config 1, Histogram, Average, the two heavy-hitter workloads) under `extra`")
     ap.add_argument("--host-buffers", choices=("pageable", "pinned"), default=None,
                     help="time the host-buffer entry points instead (wh_prio3_prepare_batch + wh_prio3_aggregate): reports start in host "
                          "memory, tags / ids / status / aggregate end there; PCIe inclusive")
@@ -148,6 +148,19 @@ def main():
                                      "reports_per_gpu": r["config"]["reports_per_gpu"], "status_nonzero": r["config"]["status_nonzero"],
                                      "sort_and_keep_mask_in_step": r["config"]["sort_and_keep_mask_in_step"],
                                      "valu_frac": r["valu"]["frac"], "roofline": {k: r["roofline"].get(k) for k in ("bound", "kernel", "frac", "achieved", "peak", "unit")},
+                                     "kernels": {k: round(v["ms_per_step"], 4) for k, v in r["kernels"].items()}}
+        # the heavy-hitter servers' step (BASELINE configs 4 and 5: eval_and_check of every key chain + the sketch sums), every key
+        # chain of the step distinct
+        import copy
+        for name in ("hh_t0.01", "hh_t0.001"):
+            a2 = copy.copy(args)
+            a2.workload, a2.steps, a2.warmup, a2.reports_per_gpu = name, max(args.steps, 5), max(args.warmup, 2), 0
+            r = bench_hh(a2, rank, local_rank, world, dev, backend, emit=False)
+            result["extra"][name] = {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
+                                     "steps": r["steps"], "warmup": r["warmup"], "workload": r["config"]["workload"],
+                                     "key_chains_per_step_per_gpu": r["config"]["key_chains_per_step_per_gpu"],
+                                     "distinct_key_chains": r["config"]["distinct_key_chains"], "status_nonzero": r["config"]["status_nonzero"],
+                                     "roofline": {k: r["roofline"].get(k) for k in ("bound", "kernel", "frac", "achieved", "peak", "unit")},
                                      "kernels": {k: round(v["ms_per_step"], 4) for k, v in r["kernels"].items()}}
     if rank == 0 and result is not None:
         print(json.dumps(result))
@@ -567,7 +580,7 @@ def bench_host_buffers(args, vdaf, params, n, d_blob, d_off, keep, world, rank):
     return result if rank == 0 else None
 
 
-def bench_hh(args, rank, local_rank, world, dev, backend):
+def bench_hh(args, rank, local_rank, world, dev, backend, emit=True):
     """server-hh's expansion + aggregation (server-hh/src/main.rs:236-283): per repetition, eval_and_check of every client's
     key chain, then the sum of the kept clients' bucket vectors; across GPUs an integer all-reduce of the sketches."""
     import torch.distributed as dist
@@ -730,10 +743,11 @@ def bench_hh(args, rank, local_rank, world, dev, backend):
                              "(tools/aes_microbench.hip, profiles/r1_aes_microbench.txt); frac is k_hh_main's"},
             "kernels": kernels,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and emit:
             result["cpu_baseline"] = cpu_baseline_hh(depth, keys, reps, clients, max(1, min(16, os.cpu_count() or 1)), args.cpu_seconds)
-        print(json.dumps(result))
-    if world > 1:
+        if emit:
+            print(json.dumps(result))
+    if world > 1 and emit:
         dist.barrier()
         dist.destroy_process_group()
     h.close()
