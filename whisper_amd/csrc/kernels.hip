@@ -507,6 +507,11 @@ struct QueryShared {      // behind the weight rows in LDS
 #ifndef WH_Q_WAVES
 #define WH_Q_WAVES 3
 #endif
+#ifdef WH_Q_EXP                             // timing experiments (results invalid): a phase left out
+#define WH_Q_SKIP(n_) (WH_Q_EXP == (n_))
+#else
+#define WH_Q_SKIP(n_) false
+#endif
 template <bool HIST, bool BASE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WH_Q_WAVES, WH_Q_WAVES))) k_query_psum(Prio3Dev P, Workspace W, uint8_t *tags,
                                                     uint8_t *out_shares, int32_t *status) {
@@ -679,7 +684,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WH_Q_W
             }
         }
         // this lane's slot: seeds (call 0), differences against the public proof, RLC
-        if (k < P.chunk) {
+        if (k < P.chunk && !WH_Q_SKIP(6)) {
             // every load of this block first, in one go: left to the compiler they sit in front of their uses, one memory
             // latency after the other (six per slot block)
             F128 s_even = ld128g(d.proof2 + 16ull * (2 * k)), s_odd = ld128g(d.proof2 + 16ull * (2 * k + 1));
@@ -722,7 +727,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WH_Q_W
 
     // first wave: gadget polynomial G = proof2[arity ..]: G(r) and <s, G>
     F128 g_at_r = f_zero(), v0 = f_zero();
-    if (wave == 0) {
+    if (wave == 0 && !WH_Q_SKIP(5)) {
         const uint8_t *G = d.proof2 + 16ull * P.arity;
         Lazy cg, cv;
         f_lazy_zero(cg);
@@ -767,7 +772,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WH_Q_W
     // sum_k pp[1+2k] pp[2+2k] == pp[1+arity]; Leader only: the proof share of run 1 is hashed,
     // never evaluated, but it still has to decode
     if (!BASE && wave == S - 1) {
-        if (leader)
+        if (leader && !WH_Q_SKIP(4))
             for (uint32_t e = lane; e < P.proof_len; e += 64) {
                 F128 v = ld128g(d.proof1 + 16ull * e);
                 bad |= !f_in_range(v.lo, v.hi);
