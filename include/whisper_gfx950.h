@@ -108,7 +108,10 @@ int32_t wh_ctx_unlock(wh_ctx *ctx);
  *   status      n      int32 per report
  * A report that does not decode (status != 0 from the parse: short, bad aggregator id, wrong num_queries) gets a zero tag, a
  * zero testing id and a zero out share, whatever the buffers held before.
- * The out shares (truncated measurement shares) stay in the context for wh_prio3_aggregate*. */
+ * The out shares (truncated measurement shares) stay in the context for wh_prio3_aggregate*.
+ * Limit (all verifying entry points: this one, prepare_init, wh_flp_query_batch): the query kernel keeps 48 B per gadget call
+ * in LDS, at most 160 KiB with the truncate staging of its wavefronts -- 3 228 calls at chunk_length <= 64, 3 047 up to 128,
+ * 2 684 above; a circuit with more (a chunk length far below sqrt(input_len)) returns WH_ERR_UNSUPPORTED. */
 int32_t wh_prio3_prepare_batch_dev(wh_ctx *ctx, const uint8_t verify_key[16], const uint8_t *d_blob,
                                    const uint64_t *d_offsets, uint64_t n, uint8_t *d_tags,
                                    uint8_t *d_testing_ids, int32_t *d_status);

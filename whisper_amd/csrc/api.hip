@@ -312,7 +312,12 @@ QueryLaunch query_launch(const wh_ctx *c, bool base) {
                                : (hist ? k_query_psum_tiny<true, false> : k_query_psum_tiny<false, false>);
     else if (base) q.fn = hist ? k_query_psum<true, true> : k_query_psum<false, true>;
     else q.fn = hist ? k_query_psum<true, false> : k_query_psum<false, false>;
-    if (q.lds > 64 * 1024) q.fn = nullptr;
+    // more than the 64 KiB every kernel may ask for: gfx950 gives a workgroup up to 160 KiB on request (then one workgroup
+    // per CU: thousands of gadget calls, i.e. a chunk length far below sqrt(input_len), are slow but verified all the same)
+    if (q.lds > 64 * 1024 &&
+        (q.lds > 160 * 1024 ||
+         hipFuncSetAttribute(reinterpret_cast<const void *>(q.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds) != hipSuccess))
+        q.fn = nullptr;
     return q;
 }
 static inline dim3 query_grid(const QueryLaunch &q, uint32_t nb) { return dim3((nb + q.per_block - 1) / q.per_block); }
@@ -497,7 +502,7 @@ static int32_t prepare_begin(wh_ctx *c, const uint8_t verify_key[16], uint64_t n
     }
     memcpy(&pl.vk0, verify_key, 8); memcpy(&pl.vk1, verify_key + 8, 8);
     pl.q = query_launch(c, false);
-    if (!pl.q.fn) { c->err = "circuit has too many gadget calls for the query kernel's LDS rows"; return WH_ERR_UNSUPPORTED; }
+    if (!pl.q.fn) { c->err = "circuit has too many gadget calls for the query kernel's LDS rows (48 B per call in 160 KiB)"; return WH_ERR_UNSUPPORTED; }
     return WH_OK;
 }
 
@@ -659,7 +664,7 @@ int32_t wh_prio3_prepare_init_batch_dev(wh_ctx *c, const uint8_t verify_key[16],
     memcpy(&vk0, verify_key, 8); memcpy(&vk1, verify_key + 8, 8);
     c->producer = wh_ctx::NONE; c->n_last = 0; c->init_finished = false;
     const QueryLaunch q = query_launch(c, true);
-    if (!q.fn) { c->err = "circuit has too many gadget calls for the query kernel's LDS rows"; return WH_ERR_UNSUPPORTED; }
+    if (!q.fn) { c->err = "circuit has too many gadget calls for the query kernel's LDS rows (48 B per call in 160 KiB)"; return WH_ERR_UNSUPPORTED; }
     if (!n) { c->d_status_last = nullptr; c->producer = wh_ctx::PREPARE_INIT; c->init_finished = true; return WH_OK; }   // nothing to decide
     uint8_t *d_out = reinterpret_cast<uint8_t *>(c->d_out_shares);
     const uint64_t prep_row = 16ull * (z.verifier_len + 1);
@@ -776,7 +781,7 @@ static int32_t flp_query_dev(wh_ctx *c, const uint8_t *d_in, const uint8_t *d_pf
     c->n_last = n; c->d_status_last = nullptr; c->producer = wh_ctx::FLP_QUERY;
     if (!n) return WH_OK;
     const QueryLaunch q = query_launch(c, true);
-    if (!q.fn) { c->err = "circuit has too many gadget calls for the query kernel's LDS rows"; return WH_ERR_UNSUPPORTED; }
+    if (!q.fn) { c->err = "circuit has too many gadget calls for the query kernel's LDS rows (48 B per call in 160 KiB)"; return WH_ERR_UNSUPPORTED; }
     HIPCHK(c, hipMemsetAsync(c->W.counters, 0, 64, c->stream));
     const uint32_t nb = (uint32_t)n, npad = (nb + 255) / 256 * 256;
     hipLaunchKernelGGL(k_flp_setup, dim3(npad / 256), dim3(256), 0, c->stream, c->P, c->W, d_in, d_pf, d_qr, d_jr, nb, d_status);
