@@ -1,7 +1,10 @@
 """Randomised differential run of the batched Prio3 path against the oracle (a tool, not a test: minutes of GPU time).
 Random circuits and shapes, 2..4 aggregators, batches that mix aggregator ids in random order and random sizes around the
 wavefront boundaries, truncated / mutated reports, both pipelines; with `base` as third argument the un-batched (draft-07)
-prepare_init path with keys of mixed aggregator ids.  Usage on the GPU box: python tools/stress_prio3.py [seconds] [seed] [base]"""
+prepare_init path with keys of mixed aggregator ids; with `wide` (`widebase` for the un-batched path) shapes from far wider ranges (bits to 127, vectors to 400,
+histograms to 5 000, chunk lengths from 1 to 1 000) in small batches, where the only refusal allowed is the documented one
+(more gadget calls than the query kernel's 160 KiB of LDS rows hold).
+Usage on the GPU box: python tools/stress_prio3.py [seconds] [seed] [base|wide|widebase]"""
 import os
 import sys
 import time
@@ -18,11 +21,35 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t0 = time.time()
 rounds = reports_checked = 0
-base_mode = len(sys.argv) > 3 and sys.argv[3] == "base"
+base_mode = len(sys.argv) > 3 and sys.argv[3] in ("base", "widebase")
+wide_mode = len(sys.argv) > 3 and sys.argv[3] in ("wide", "widebase")
+refused = 0
+
+
+def wide_chunk(input_len):
+    k = int(rng.integers(0, 4))
+    if k == 0:
+        return int(rng.integers(1, 11))
+    if k == 1:
+        return int(rng.choice([63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 512, 1000]))
+    root = max(1, int(input_len ** 0.5))
+    return int(rng.integers(max(1, root // 2), 2 * root + 2))
+
+
+def calls_limit(chunk):           # include/whisper_gfx950.h, wh_prio3_prepare_batch_dev
+    return 3228 if chunk <= 64 else 3047 if chunk <= 128 else 2684
+
+
 while base_mode and time.time() - t0 < budget:
     circ = int(rng.integers(0, 3))
     na = int(rng.integers(2, 6))
-    if circ == W.SUMVEC:
+    if wide_mode and circ == W.SUMVEC:
+        bits = int(rng.choice([1, 2, 7, 16, 31, 32, 33, 64, 100, 127])); ln = int(rng.integers(1, 201)); ch = wide_chunk(bits * ln)
+    elif wide_mode and circ == W.HISTOGRAM:
+        bits = 0; ln = int(rng.integers(2, 3001)); ch = wide_chunk(ln)
+    elif wide_mode:
+        bits = int(rng.integers(1, 128)); ln = ch = 0
+    elif circ == W.SUMVEC:
         bits = int(rng.choice([1, 3, 8, 16])); ln = int(rng.integers(1, 24)); ch = int(rng.integers(1, 40))
     elif circ == W.HISTOGRAM:
         bits = 0; ln = int(rng.integers(2, 100)); ch = int(rng.integers(1, 50))
@@ -32,8 +59,12 @@ while base_mode and time.time() - t0 < budget:
         p = W.Prio3Params(circ, bits, ln, ch, na)
     except W.WhError:
         continue
+    if wide_mode and p.calls > 4000:
+        continue
     op = O.params(circ, bits, ln, ch, na)
-    n = int(rng.choice([1, 63, 65, 130, 200]))
+    n = int(rng.choice([1, 3, 65])) if wide_mode else int(rng.choice([1, 63, 65, 130, 200]))
+    if wide_mode and p.input_len > 4000:
+        n = min(n, 3)
     seed = int(rng.integers(0, 1 << 30))
     meas = measurements(p, n, seed)
     vk = bytes(det(b"bvk%d" % seed, 16))
@@ -53,7 +84,14 @@ while base_mode and time.time() - t0 < budget:
         keys.append(key)
     vdaf = W.Prio3(p)
     try:
-        prep, status = vdaf.prepare_init_encoded_keys(vk, keys)
+        try:
+            prep, status = vdaf.prepare_init_encoded_keys(vk, keys)
+        except W.WhError as e:
+            if e.code == -103 and circ != W.AVERAGE and p.calls > calls_limit(ch):     # the documented refusal
+                refused += 1
+                continue
+            print("REFUSED base", dict(circ=circ, bits=bits, ln=ln, ch=ch, na=na, n=n, seed=seed, calls=p.calls), e, flush=True)
+            sys.exit(1)
         outs = vdaf.out_shares()
         for j in range(n):
             if want[j] is None:
@@ -69,12 +107,19 @@ while base_mode and time.time() - t0 < budget:
     if rounds % 20 == 0:
         print(f"{rounds} batches, {reports_checked} keys, {time.time() - t0:.0f} s", flush=True)
 if base_mode:
-    print(f"ok (un-batched): {rounds} batches, {reports_checked} keys checked against the oracle in {time.time() - t0:.0f} s")
+    print(f"ok (un-batched): {rounds} batches, {reports_checked} keys checked against the oracle in {time.time() - t0:.0f} s"
+          + (f" ({refused} shapes beyond the documented gadget-call limit refused)" if wide_mode else ""))
     sys.exit(0)
 while time.time() - t0 < budget:
     circ = int(rng.integers(0, 3))
     na = int(rng.choice([2, 2, 3, 4]))
-    if circ == W.SUMVEC:
+    if wide_mode and circ == W.SUMVEC:
+        bits = int(rng.choice([1, 2, 7, 16, 31, 32, 33, 64, 100, 127])); ln = int(rng.integers(1, 401)); ch = wide_chunk(bits * ln)
+    elif wide_mode and circ == W.HISTOGRAM:
+        bits = 0; ln = int(rng.integers(2, 5001)); ch = wide_chunk(ln)
+    elif wide_mode:
+        bits = int(rng.integers(1, 128)); ln = ch = 0
+    elif circ == W.SUMVEC:
         bits = int(rng.choice([1, 2, 5, 8, 16, 33])); ln = int(rng.integers(1, 40)); ch = int(rng.integers(1, 70))
     elif circ == W.HISTOGRAM:
         bits = 0; ln = int(rng.integers(2, 200)); ch = int(rng.integers(1, 80))
@@ -84,8 +129,12 @@ while time.time() - t0 < budget:
         p = W.Prio3Params(circ, bits, ln, ch, num_aggregators=na)
     except W.WhError:
         continue
+    if wide_mode and p.calls > 4000:          # far beyond the limit (and the context's tables grow with calls^2)
+        continue
     op = O.params(circ, bits, ln, ch, num_aggregators=na)
-    n = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, 200, 257, 300]))
+    n = int(rng.choice([1, 3, 65])) if wide_mode else int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, 200, 257, 300]))
+    if wide_mode and p.input_len > 8000:
+        n = min(n, 3)
     seed = int(rng.integers(0, 1 << 30))
     meas = measurements(p, n, seed)
     nonces = det(b"sn%d" % seed, 16 * n).reshape(n, 16)
@@ -111,7 +160,14 @@ while time.time() - t0 < budget:
         for path in ("default", "long_share"):
             if path == "long_share":
                 vdaf.set_option("chain_max_input_len", 0); vdaf.set_option("query_tiny", 0)
-            t, ids, status = vdaf.prepare_encoded_keys(VK, reports)
+            try:
+                t, ids, status = vdaf.prepare_encoded_keys(VK, reports)
+            except W.WhError as e:
+                if e.code == -103 and circ != W.AVERAGE and p.calls > calls_limit(ch):     # the documented refusal
+                    refused += 1
+                    break
+                print("REFUSED", dict(circ=circ, bits=bits, ln=ln, ch=ch, na=na, n=n, seed=seed, path=path, calls=p.calls), e, flush=True)
+                sys.exit(1)
             outs = vdaf.out_shares()
             ok = status == 0
             good = (np.array_equal(status, o_status) and np.array_equal(t[ok], o_t[ok]) and np.array_equal(ids[ok], o_ids[ok])
@@ -125,4 +181,5 @@ while time.time() - t0 < budget:
     rounds += 1; reports_checked += 2 * n
     if rounds % 20 == 0:
         print(f"{rounds} batches, {reports_checked} reports, {time.time() - t0:.0f} s", flush=True)
-print(f"ok: {rounds} batches, {reports_checked} reports checked against the oracle in {time.time() - t0:.0f} s")
+print(f"ok: {rounds} batches, {reports_checked} reports checked against the oracle in {time.time() - t0:.0f} s"
+      + (f" ({refused} shapes beyond the documented gadget-call limit refused)" if wide_mode else ""))
