@@ -30,7 +30,8 @@ enum { WH_SUMVEC = 0, WH_HISTOGRAM = 1, WH_AVERAGE = 2 };
  * new_average_256 (vdaf/prio3.rs:150-165, 300-313, 360-380) as the servers call them
  * (server-batch-prio3/src/main.rs:249-257).  The servers run two aggregators (Alice and Bob); the batched path, like
  * Prio3::prepare_batched (prio3.rs:2843-2855; its own test runs three, :3077-3085), and the draft-07 prepare_init path
- * take 2..255.  Aggregator 0 is the Leader (explicit shares), 1.. are Helpers (seeds).  The GPU sharder
+ * take 2..254 (check_num_aggregators, vdaf/prio3.rs:2945-2957; a single aggregator, legal there, is refused:
+ * WH_ERR_PARAM).  Aggregator 0 is the Leader (explicit shares), 1.. are Helpers (seeds).  The GPU sharder
  * (wh_client_shard_many_gpu) is built for two. */
 typedef struct {
     uint32_t circuit;         /* WH_SUMVEC | WH_HISTOGRAM | WH_AVERAGE */

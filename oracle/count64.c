@@ -84,7 +84,7 @@ size_t wo_count_leader_share_len(void) { return 48; }
 int wo_count_shard(uint32_t num_aggregators, uint64_t meas, const uint8_t nonce[16], const uint8_t *rand, uint8_t *leader_share,
                    uint8_t *helper_shares) {
     (void)nonce;
-    if (num_aggregators < 2 || num_aggregators > 255 || meas > 1) return WO_ERR_PARAM;
+    if (num_aggregators < 2 || num_aggregators > 254 || meas > 1) return WO_ERR_PARAM;   /* check_num_aggregators, prio3.rs:2945-2957 */
     uint64_t x = meas, leader_meas = x, proof[5], prove_rand[2], t[5];
     const uint8_t *rnd = rand;
     for (uint32_t a = 1; a < num_aggregators; a++) {

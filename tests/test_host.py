@@ -42,6 +42,12 @@ def test_sizes_match_oracle():
         W.Prio3Params(0, 16, 0, 4)
     with pytest.raises(W.WhError):
         W.Prio3Params(0, 16, 4, 4, num_aggregators=1)
+    # check_num_aggregators (vdaf/prio3.rs:2945-2957): at most 254, in the library and in the oracle
+    assert W.Prio3Params(0, 16, 4, 4, num_aggregators=254).sizes.leader_report_len == O.sizes(O.params(0, 16, 4, 4, num_aggregators=254)).leader_report_len
+    with pytest.raises(W.WhError):
+        W.Prio3Params(0, 16, 4, 4, num_aggregators=255)
+    with pytest.raises(ValueError):
+        O.sizes(O.params(0, 16, 4, 4, num_aggregators=255))
     # a public share carries one 16-byte part per aggregator, twice per report (vdaf.rs:148-162)
     for na in (3, 5):
         p3, s3 = W.Prio3Params(0, 16, 4, 4, num_aggregators=na), O.sizes(O.params(0, 16, 4, 4, num_aggregators=na))

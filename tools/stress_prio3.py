@@ -42,7 +42,7 @@ def calls_limit(chunk):           # include/whisper_gfx950.h, wh_prio3_prepare_b
 
 while base_mode and time.time() - t0 < budget:
     circ = int(rng.integers(0, 3))
-    na = int(rng.integers(2, 6))
+    na = int(rng.choice([2, 3, 5, 17, 254])) if wide_mode else int(rng.integers(2, 6))
     if wide_mode and circ == W.SUMVEC:
         bits = int(rng.choice([1, 2, 7, 16, 31, 32, 33, 64, 100, 127])); ln = int(rng.integers(1, 201)); ch = wide_chunk(bits * ln)
     elif wide_mode and circ == W.HISTOGRAM:
@@ -112,7 +112,7 @@ if base_mode:
     sys.exit(0)
 while time.time() - t0 < budget:
     circ = int(rng.integers(0, 3))
-    na = int(rng.choice([2, 2, 3, 4]))
+    na = int(rng.choice([2, 2, 3, 4, 9, 64, 254])) if wide_mode else int(rng.choice([2, 2, 3, 4]))
     if wide_mode and circ == W.SUMVEC:
         bits = int(rng.choice([1, 2, 7, 16, 31, 32, 33, 64, 100, 127])); ln = int(rng.integers(1, 401)); ch = wide_chunk(bits * ln)
     elif wide_mode and circ == W.HISTOGRAM:

@@ -239,7 +239,7 @@ extern "C" {
 
 int32_t wh_prio3_count_prepare_init_batch(wh_ctx *c, uint32_t num_aggregators, const uint8_t verify_key[16], const uint8_t *blob,
                                           const uint64_t *offsets, uint64_t n, uint8_t *prep_shares, int32_t *status) {
-    if (!c || !verify_key || (n && (!blob || !offsets || !prep_shares || !status)) || num_aggregators < 2 || num_aggregators > 255 ||
+    if (!c || !verify_key || (n && (!blob || !offsets || !prep_shares || !status)) || num_aggregators < 2 || num_aggregators > 254 ||
         n > 0xfffffff0ull) return WH_ERR_PARAM;
     std::lock_guard<std::recursive_mutex> lk(ctx_mutex(c));
     C_HIPCHK(c, hipSetDevice(ctx_device(c)));
@@ -266,7 +266,7 @@ int32_t wh_prio3_count_prepare_init_batch(wh_ctx *c, uint32_t num_aggregators, c
 }
 
 int32_t wh_prio3_count_prepare_finish_batch(wh_ctx *c, uint32_t num_aggregators, const uint8_t *const *prep_shares, uint64_t n, int32_t *status) {
-    if (!c || num_aggregators < 2 || num_aggregators > 255 || (n && (!prep_shares || !status))) return WH_ERR_PARAM;
+    if (!c || num_aggregators < 2 || num_aggregators > 254 || (n && (!prep_shares || !status))) return WH_ERR_PARAM;
     std::lock_guard<std::recursive_mutex> lk(ctx_mutex(c));
     Count64 *S = state_of(c);
     if (!S->valid || S->n_last != n) { ctx_set_error(c, "wh_prio3_count_prepare_finish_batch: no prepare_init batch of this size in the context"); return WH_ERR_STATE; }

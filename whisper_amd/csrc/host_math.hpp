@@ -19,7 +19,7 @@ struct HostSizes {
 };
 
 inline int32_t host_sizes(const wh_prio3_params &p, HostSizes &s) {
-    if (p.num_aggregators < 2 || p.num_aggregators > 255) return WH_ERR_PARAM;
+    if (p.num_aggregators < 2 || p.num_aggregators > 254) return WH_ERR_PARAM;   // check_num_aggregators, prio3.rs:2945-2957 (1 is legal there: no sharing, refused here)
     switch (p.circuit) {
     case WH_SUMVEC:
         if (!p.bits || !p.len || !p.chunk || p.bits > 127 || (uint64_t)p.bits * p.len > (1u << 24)) return WH_ERR_PARAM;
