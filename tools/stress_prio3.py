@@ -3,7 +3,8 @@ Random circuits and shapes, 2..4 aggregators, batches that mix aggregator ids in
 wavefront boundaries, truncated / mutated reports, both pipelines; with `base` as third argument the un-batched (draft-07)
 prepare_init path with keys of mixed aggregator ids; with `wide` (`widebase` for the un-batched path) shapes from far wider ranges (bits to 127, vectors to 400,
 histograms to 5 000, chunk lengths from 1 to 1 000) in small batches, where the only refusal allowed is the documented one
-(more gadget calls than the query kernel's 160 KiB of LDS rows hold).
+(more gadget calls than the query kernel's 160 KiB of LDS rows hold).  Half of the batches run with random settings of the
+context's launch-shape knobs (sub-batch size, side streams, prefetch, H2D chunk), on which results must not depend.
 Usage on the GPU box: python tools/stress_prio3.py [seconds] [seed] [base|wide|widebase]"""
 import os
 import sys
@@ -34,6 +35,16 @@ def wide_chunk(input_len):
         return int(rng.choice([63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 512, 1000]))
     root = max(1, int(input_len ** 0.5))
     return int(rng.integers(max(1, root // 2), 2 * root + 2))
+
+
+def random_knobs(vdaf):
+    """Results never depend on a knob (include/whisper_gfx950.h): draw some."""
+    if rng.integers(0, 2):
+        return
+    vdaf.set_option("max_subbatch", int(rng.choice([0, 64, 65, 100, 128])))
+    for name in ("side_stream", "hash_b_side", "third_stream", "base_paired", "chain_prefetch"):
+        vdaf.set_option(name, int(rng.integers(0, 2)))
+    vdaf.set_option("host_chunk_mb", int(rng.choice([1, 2, 2048])))
 
 
 def calls_limit(chunk):           # include/whisper_gfx950.h, wh_prio3_prepare_batch_dev
@@ -83,6 +94,9 @@ while base_mode and time.time() - t0 < budget:
             want.append((rc, wp, wo))
         keys.append(key)
     vdaf = W.Prio3(p)
+    random_knobs(vdaf)
+    if rng.integers(0, 3) == 0:
+        vdaf.set_option("chain_max_input_len", 0)
     try:
         try:
             prep, status = vdaf.prepare_init_encoded_keys(vk, keys)
@@ -156,6 +170,7 @@ while time.time() - t0 < budget:
     blob, offsets = blob_of(reports)
     o_t, o_ids, o_status, o_outs = O.prio3_prepare_batch(op, VK, blob, offsets, nthreads=16)
     vdaf = W.Prio3(p)
+    random_knobs(vdaf)
     try:
         for path in ("default", "long_share"):
             if path == "long_share":
