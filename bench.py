@@ -135,7 +135,7 @@ def main():
     if args.workload in HH_WORKLOADS:
         return bench_hh(args, rank, local_rank, world, dev, backend)
     result = bench_prio3(args, args.workload, args.reports_per_gpu, args.steps, args.warmup, rank, local_rank, world, dev, backend,
-                         cpu=not args.no_cpu_baseline)
+                         cpu=not args.no_cpu_baseline and world == 1)      # the CPU baseline: rank 0 at N = 1 only
     if (rank == 0 and world == 1 and not args.no_extra and not args.no_cpu_baseline and not args.host_buffers and args.workload == "sumvec_large"
             and not args.reports_per_gpu):
         # the other Prio3 configurations of BASELINE.json (config 1 = the reference's shipped JSON, config 2 = Histogram) and the
@@ -743,7 +743,7 @@ def bench_hh(args, rank, local_rank, world, dev, backend, emit=True):
                              "(tools/aes_microbench.hip, profiles/r1_aes_microbench.txt); frac is k_hh_main's"},
             "kernels": kernels,
         }
-        if not args.no_cpu_baseline and emit:
+        if not args.no_cpu_baseline and emit and world == 1:
             result["cpu_baseline"] = cpu_baseline_hh(depth, keys, reps, clients, max(1, min(16, os.cpu_count() or 1)), args.cpu_seconds)
         if emit:
             print(json.dumps(result))
