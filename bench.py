@@ -679,6 +679,8 @@ def bench_hh(args, rank, local_rank, world, dev, backend, emit=True):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     n_bad_status = int((d_status != 0).sum().item())
+    import hashlib
+    sketch_sha = hashlib.sha256(d_acc.cpu().numpy().tobytes()).hexdigest()      # the last step's (combined) sketches
     result = None
     if rank == 0:
         kernels = {k: {"ms_per_step": ms / args.steps, "launches_per_step": cnt / args.steps} for k, (ms, cnt) in ktimes.items() if cnt}
@@ -719,6 +721,7 @@ def bench_hh(args, rank, local_rank, world, dev, backend, emit=True):
             "config": {"workload": wl["desc"], "clients_per_gpu": clients, "repetitions": reps, "buckets": N,
                        "key_chains_per_step_per_gpu": n, "key_chain_bytes": ln, "distinct_key_chains": K, "key_chains_tiled": K != n,
                        "inputs": "resident in HBM", "status_nonzero": n_bad_status, "client_gen_s": round(t_gen, 2),
+                       "sketch_sha256": sketch_sha,
                        "parallelism": f"key chains sharded over {world} GPU(s); integer all-reduce of the sketches",
                        "combine": ("none (one GPU)" if world == 1 else "wh_comm: the library's RCCL binding (wh_hh_allreduce_u32_dev)" if wh_comm
                                    else f"torch.distributed all_reduce ({backend})" + (f"; wh_comm unavailable: {wh_comm_why}" if wh_comm_why else ""))},
