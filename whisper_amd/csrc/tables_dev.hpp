@@ -61,23 +61,35 @@ __device__ __forceinline__ void weights_and_tables(const Prio3Dev &P, const Work
                                                    const F128 &rm, const F128 &rho) {
     // Barycentric weights for run 2 (run 1's verifier never reaches the tag, prio3.rs:2713):
     //   L_j(r) = (r^m - 1)/m * w^j / (r - w^j),  j = 0..calls,  w = omega_m.
-    // One inversion per report: prefix products of (r - w^j) are parked in the weight row.
+    // One inversion per report: prefix products of (r - w^j) are parked in the weight row.  The roots are fetched a step
+    // ahead of their use, the parked products two.
     F128 *L = W.weights + (uint64_t)i * P.n_weights;
     F128 acc = f_one();
-    for (uint32_t j = 0; j < P.n_weights; j++) {
-        L[j] = acc;
-        acc = f_mul(acc, f_sub(r, P.omega[j]));
+    {
+        F128 wn = P.omega[0];
+        for (uint32_t j = 0; j < P.n_weights; j++) {
+            const F128 w = wn;
+            if (j + 1 < P.n_weights) wn = P.omega[j + 1];
+            L[j] = acc;
+            acc = f_mul(acc, f_sub(r, w));
+        }
     }
     // the common factor (r^m - 1)/m rides on the running inverse: three multiplications per weight
     F128 inv = f_mul(f_inv(acc), f_mul(f_sub(rm, f_one()), P.m_inv));
-    F128 parked = L[P.n_weights - 1];          // the next prefix product is fetched a step ahead of its use
-    for (uint32_t j = P.n_weights; j-- > 0;) {
-        F128 w = P.omega[j];
-        const F128 pre = parked;
-        if (j) parked = L[j - 1];
-        F128 dinv = f_mul(inv, pre);           // (r^m - 1)/m / (r - w^j)
-        inv = f_mul(inv, f_sub(r, w));
-        L[j] = f_mul(w, dinv);
+    {
+        // prefix products and roots two steps ahead of their use: a step is three multiplications, a row read back after the
+        // inversion comes from beyond L2
+        const uint32_t nw = P.n_weights;
+        F128 p0 = L[nw - 1], p1 = nw > 1 ? L[nw - 2] : f_zero();
+        F128 w0 = P.omega[nw - 1], w1 = nw > 1 ? P.omega[nw - 2] : f_zero();
+        for (uint32_t j = nw; j-- > 0;) {
+            const F128 pre = p0, w = w0;
+            p0 = p1; w0 = w1;
+            if (j >= 2) { p1 = L[j - 2]; w1 = P.omega[j - 2]; }
+            F128 dinv = f_mul(inv, pre);           // (r^m - 1)/m / (r - w^j)
+            inv = f_mul(inv, f_sub(r, w));
+            L[j] = f_mul(w, dinv);
+        }
     }
     // what the query kernels would otherwise compute with a whole wavefront per value: small power tables of rho and r
     RepPow *pw = &W.pows[i];
@@ -98,10 +110,11 @@ __device__ __forceinline__ void weights_and_tables(const Prio3Dev &P, const Work
         const F128 rc = f_pow_u32(rho, P.chunk);
         uint4 *wl = reinterpret_cast<uint4 *>(W.wlimbs + (uint64_t)i * 12 * P.calls);
         F128 pj = f_one(), sumL = f_zero();
-        F128 lnext = L[1];
+        F128 lnext = L[1], lnext2 = P.calls > 1 ? L[2] : f_zero();      // two steps ahead, as above
         for (uint32_t j = 1; j <= P.calls; j++) {
             const F128 l = lnext;
-            if (j < P.calls) lnext = L[j + 1];
+            lnext = lnext2;
+            if (j + 1 < P.calls) lnext2 = L[j + 2];
             const F128 m = f_mul(l, pj);
             sumL = f_add(sumL, l);
             uint32_t tl[5], tm[5];
